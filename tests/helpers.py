@@ -1,0 +1,59 @@
+"""Shared helpers for the parity tests: golden-fixture summaries and tolerance checks."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# fp32 parity tolerance stated by the north star: 1e-5 relative (norm-wise for large tensors,
+# elementwise with an absolute floor for sampled values).
+RTOL = 1e-5
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def summary(t: torch.Tensor, nsamp: int = 256):
+    a = t.detach().to("cpu", torch.float64).reshape(-1).numpy()
+    if a.size <= 4096:
+        samp = a.astype(np.float32)
+    else:
+        idx = (np.arange(nsamp, dtype=np.int64) * (a.size // nsamp) + (a.size // nsamp) // 2)
+        samp = a[idx].astype(np.float32)
+    return np.array([a.sum(), (a * a).sum()], dtype=np.float64), samp
+
+
+def check_summary(gold, name: str, t: torch.Tensor, rtol: float = RTOL, what: str = ""):
+    """Compare tensor `t` against the (sum, sumsq, strided samples) the fixture holds for `name`.
+    Sampled values must agree to rtol relative to the tensor's RMS (norm-wise), the sum of
+    squares to 2*rtol-ish relative, the plain sum to rtol * sqrt(n * sumsq) (its natural scale)."""
+    stat, samp = summary(t)
+    gstat, gsamp = gold[name + "#stat"], gold[name + "#samp"]
+    n = t.numel()
+    rms = float(np.sqrt(max(gstat[1], 1e-300) / n))
+    err = float(np.max(np.abs(samp.astype(np.float64) - gsamp.astype(np.float64)))) if samp.size else 0.0
+    assert err <= rtol * max(rms, 1e-30) * 4 + 1e-12, f"{what}{name}: sample err {err:.3e} vs rms {rms:.3e}"
+    assert abs(stat[1] - gstat[1]) <= 4 * rtol * gstat[1] + 1e-20, f"{what}{name}: sumsq {stat[1]} vs {gstat[1]}"
+    scale = np.sqrt(n * max(gstat[1], 1e-300))
+    assert abs(stat[0] - gstat[0]) <= rtol * scale + 1e-12, f"{what}{name}: sum {stat[0]} vs {gstat[0]}"
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """Norm-wise relative error |a-b| / |b| in fp64."""
+    a = a.detach().to("cpu", torch.float64)
+    b = b.detach().to("cpu", torch.float64)
+    den = float(b.norm())
+    num = float((a - b).norm())
+    return num / den if den > 0 else num
+
+
+def max_rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / rms(b): elementwise error measured against the tensor's own scale."""
+    a = a.detach().to("cpu", torch.float64)
+    b = b.detach().to("cpu", torch.float64)
+    rms = float(b.pow(2).mean().sqrt())
+    return float((a - b).abs().max()) / (rms if rms > 0 else 1.0)
