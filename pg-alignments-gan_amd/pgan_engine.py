@@ -1,0 +1,443 @@
+"""Fused DCWGAN-GP training-step engine: buffer layout + op order on top of the HIP C-ABI.
+
+One Engine owns, on one GPU, the generator and discriminator parameters (flat fp32 buffers
+with named views = the reference modules' state_dict entries), both Adam states, and a static
+workspace; its methods enqueue hand-written HIP kernels (pgan_hip.HipOps) on the current
+stream and never allocate after construction, so a whole iteration can be captured in a
+hipGraph.  What it computes, per reference line:
+
+  critic step     /root/reference/src/train_wgan_v2.py:534-612  (gp: layers.py:34-55, div: :60-77)
+  generator step  /root/reference/src/train_wgan_v2.py:619-634
+  Adam            /root/reference/src/train_wgan_v2.py:489-490
+
+The penalty terms are differentiated analytically instead of through an autograd graph.  With
+v = d(penalty)/d(g) held constant, grad_theta(penalty) = grad_theta sum_b JVP_x(D; v)_b, so the
+discriminator's 2-D tower is evaluated on four "streams" of samples that live side by side in
+every per-layer buffer:
+
+  gp :  [ real | fake | interpolate | tangent of interpolate ]   NS = 3B primal, NP = B penalised
+  div:  [ real | fake | tangent of real | tangent of fake ]       NS = 2B primal, NP = 2B penalised
+
+forward (primal), first-order backward (input gradient g of the penalised samples and, in gp
+mode, the Wasserstein gradients of real/fake), tangent forward of v, second-order backward of
+the penalised samples, then ONE weight-gradient pass per layer over all 4B sample slots.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+LATENT = 128
+DATA = 64
+D2_CH = (1, 64, 128, 256, 512)      # discriminator 2-D tower channels (layers.py:441-463)
+D2_HW = (64, 32, 16, 8, 4)
+D1_CH = (1, 16, 32, 64)             # discriminator 1-D tower (layers.py:470-478)
+D1_LEN = (64, 61, 58, 55)
+FEAT2 = 512 * 16
+FEAT1 = 64 * 55
+
+
+def gen_param_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
+    """state_dict entries of DC_Generator_Leaky_{Sig,Tan} (layers.py:91-140), parameters only."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    ch2 = [latent, data * 8, data * 4, data * 2, data, 1]
+    ch1 = [latent, latent // 2, latent // 4, latent // 8, latent // 16, 1]
+    for i in range(5):
+        s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i], ch2[i + 1], 4, 4)
+        if i < 4:
+            s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
+            s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
+    for i in range(5):
+        s[f"oned_conv_layers.{3 * i}.weight"] = (ch1[i], ch1[i + 1], 4)
+        if i < 4:
+            s[f"oned_conv_layers.{3 * i + 1}.weight"] = (ch1[i + 1],)
+            s[f"oned_conv_layers.{3 * i + 1}.bias"] = (ch1[i + 1],)
+    return s
+
+
+def gen_buffer_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    ch2 = [data * 8, data * 4, data * 2, data]
+    ch1 = [latent // 2, latent // 4, latent // 8, latent // 16]
+    for tower, chs in (("twod_conv_layers", ch2), ("oned_conv_layers", ch1)):
+        for i, c in enumerate(chs):
+            s[f"{tower}.{3 * i + 1}.running_mean"] = (c,)
+            s[f"{tower}.{3 * i + 1}.running_var"] = (c,)
+    return s
+
+
+def disc_param_shapes(data: int = DATA) -> Dict[str, Tuple[int, ...]]:
+    """state_dict entries of DC_Discriminator (layers.py:439-482)."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    ch2 = [1, data, data * 2, data * 4, data * 8]
+    for i in range(4):
+        s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i + 1], ch2[i], 4, 4)
+        s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
+        s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
+    for i in range(3):
+        s[f"oned_conv_layers.{3 * i}.weight"] = (D1_CH[i + 1], D1_CH[i], 4)
+        s[f"oned_conv_layers.{3 * i}.bias"] = (D1_CH[i + 1],)
+        s[f"oned_conv_layers.{3 * i + 1}.weight"] = (D1_CH[i + 1],)
+        s[f"oned_conv_layers.{3 * i + 1}.bias"] = (D1_CH[i + 1],)
+    s["out.weight"] = (1, FEAT2 + FEAT1)
+    s["out.bias"] = (1,)
+    return s
+
+
+class FlatStore:
+    """Named fp32 tensors carved out of one flat buffer (256-byte aligned slices) so that Adam,
+    gradient zeroing and the data-parallel all-reduce each touch a single contiguous range."""
+
+    def __init__(self, shapes: Dict[str, Tuple[int, ...]], device, with_opt: bool = True):
+        self.shapes = dict(shapes)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for k, sh in shapes.items():
+            n = 1
+            for d in sh:
+                n *= d
+            self.offsets[k] = off
+            off += (n + 63) // 64 * 64
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.p = self._views(self.flat)
+        if with_opt:
+            self.gflat = torch.zeros_like(self.flat)
+            self.mflat = torch.zeros_like(self.flat)
+            self.vflat = torch.zeros_like(self.flat)
+            self.g = self._views(self.gflat)
+            self.m = self._views(self.mflat)
+            self.v = self._views(self.vflat)
+        self.step = 0
+
+    def _views(self, flat):
+        out = {}
+        for k, sh in self.shapes.items():
+            n = 1
+            for d in sh:
+                n *= d
+            out[k] = flat[self.offsets[k]:self.offsets[k] + n].view(sh)
+        return out
+
+    def load(self, params: Dict[str, torch.Tensor]) -> None:
+        for k, v in self.p.items():
+            v.copy_(params[k].to(v.device, torch.float32))
+
+
+class Engine:
+    def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
+                 latent: int = LATENT, lr_d: float = 5e-5, lr_g: float = 5e-5,
+                 betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8):
+        if loss not in ("gp", "div"):
+            raise ValueError(f"loss must be 'gp' or 'div', got {loss!r}")
+        if act not in ("sigmoid", "tanh"):
+            raise ValueError(f"act must be 'sigmoid' or 'tanh', got {act!r}")
+        self.ops, self.B, self.dev = ops, int(batch), device
+        self.loss, self.act, self.lam, self.latent = loss, act, float(lam), int(latent)
+        self.act_id = 1 if act == "sigmoid" else 2
+        self.lr_d, self.lr_g, self.betas, self.eps = lr_d, lr_g, betas, eps
+        B = self.B
+        self.NS = 3 * B if loss == "gp" else 2 * B      # primal sample slots
+        self.NP = B if loss == "gp" else 2 * B          # penalised samples (tangent slots)
+        self.NT = self.NS + self.NP                     # = 4B
+        f = dict(dtype=torch.float32, device=device)
+
+        self.D = FlatStore(disc_param_shapes(), device)
+        self.G = FlatStore(gen_param_shapes(latent), device)
+        self.Gbuf = FlatStore(gen_buffer_shapes(latent), device, with_opt=False)
+        for k, v in self.Gbuf.p.items():
+            if k.endswith("running_var"):
+                v.fill_(1.0)
+        self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
+
+        NT = self.NT
+        # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
+        self.X0 = torch.zeros(NT, 1, 64, 64, **f)        # sites: primal slots then v (tangent input)
+        self.P0 = torch.zeros(2 * B, 1, 64, **f)         # positions of real | fake
+        self.dA = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
+        self.dH = [self.X0] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
+        self.dU = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
+        self.dJ = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
+        self.dStat = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]    # mu, rstd
+        self.dStatB = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(w), mean(w xhat)
+        self.dStatT = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(t), mean(xhat t)
+        self.dPG = [None] + [torch.zeros(NT, D2_CH[k], **f) for k in range(1, 5)]  # per-sample gamma partials
+        self.dPB = [None] + [torch.zeros(NT, D2_CH[k], **f) for k in range(1, 5)]
+        self.G0 = torch.zeros(max(self.NP, B), 1, 64, 64, **f)   # input gradient of penalised samples / gen step
+        self.d1A = [torch.zeros(2 * B, D1_CH[i + 1], D1_LEN[i + 1], **f) for i in range(3)]
+        self.F1 = torch.zeros(2 * B, FEAT1, **f)
+        self.dP0 = torch.zeros(B, 1, 64, **f)            # d loss / d positions (generator step)
+        self.score = torch.zeros(2 * B, **f)
+        self.coef = torch.zeros(NT, **f)                 # per-slot seed / head-gradient weights
+        self.coef_head = torch.zeros(NT, **f)
+        self.coef_top = torch.zeros(self.NP, **f)        # div: Wasserstein seed of the penalised samples
+        self.HB4 = torch.zeros(self.NP, 512, 4, 4, **f)  # div: primal adjoint entering the top stage
+        self.pen = torch.zeros(1, **f)
+        self.closs = torch.zeros(4, **f)                 # W, mean real, mean fake, penalty
+        self.gloss = torch.zeros(1, **f)
+        self.tbuf = torch.zeros(B, **f)
+        self.coef_gen = torch.full((B,), -1.0 / B, **f)
+        self.ones2B = torch.ones(2 * B, 1, **f)
+        self._init_coefs()
+
+        # ---- generator workspace ----
+        g2c = (latent, 512, 256, 128, 64, 1)
+        g2h = (1, 4, 8, 16, 32, 64)
+        self.g2c, self.g2h = g2c, g2h
+        self.Z = torch.zeros(B, latent, **f)
+        self.gA = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]   # conv outputs
+        self.gH = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]   # after BN+LReLU
+        self.gStat = [None] + [torch.zeros(2, g2c[i], **f) for i in range(1, 5)]
+        self.gdH = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]
+        self.gdA = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]
+        self.gXs = torch.zeros(B, 1, 64, 64, **f)        # generator-step output (sites)
+        self.gXp = torch.zeros(B, 1, 64, **f)
+        self.gdX = torch.zeros(B, 1, 64, 64, **f)
+        g1c = (latent, latent // 2, latent // 4, latent // 8, latent // 16, 1)
+        g1l = (1, 4, 8, 16, 32, 64)
+        self.g1c, self.g1l = g1c, g1l
+        self.hA = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
+        self.hH = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
+        self.hStat = [None] + [torch.zeros(2, g1c[i], **f) for i in range(1, 5)]
+        self.hdH = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
+        self.hdA = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
+        self.hdX = torch.zeros(B, 1, 64, **f)
+
+    # ------------------------------------------------------------------------------------------
+    def _init_coefs(self):
+        B, NS = self.B, self.NS
+        c = torch.zeros(self.NT)
+        ch = torch.zeros(self.NT)
+        if self.loss == "gp":
+            c[:B], c[B:2 * B], c[2 * B:3 * B] = -1.0 / B, 1.0 / B, 1.0
+            ch[:B], ch[B:2 * B], ch[3 * B:] = -1.0 / B, 1.0 / B, 1.0
+        else:
+            c[:2 * B] = 1.0
+            ch[:B], ch[B:2 * B], ch[2 * B:] = -1.0 / B, 1.0 / B, 1.0
+            top = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)])
+            self.coef_top.copy_(top)
+        self.coef.copy_(c)
+        self.coef_head.copy_(ch)
+        w1 = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)])
+        self.coef_w = w1.to(self.dev)
+
+    def dconv_w(self, k):
+        return self.D.p[f"twod_conv_layers.{3 * (k - 1)}.weight"]
+
+    def dgn(self, k):
+        return (self.D.p[f"twod_conv_layers.{3 * (k - 1) + 1}.weight"], self.D.p[f"twod_conv_layers.{3 * (k - 1) + 1}.bias"])
+
+    def _d1d_params(self, store):
+        cw = [store[f"oned_conv_layers.{3 * i}.weight"] for i in range(3)]
+        cb = [store[f"oned_conv_layers.{3 * i}.bias"] for i in range(3)]
+        gw = [store[f"oned_conv_layers.{3 * i + 1}.weight"] for i in range(3)]
+        gb = [store[f"oned_conv_layers.{3 * i + 1}.bias"] for i in range(3)]
+        return cw, cb, gw, gb
+
+    # ------------------------------------------------------------------------------------------
+    # generator
+    # ------------------------------------------------------------------------------------------
+    def gen_forward(self, z: torch.Tensor, out_s: torch.Tensor, out_p: torch.Tensor) -> None:
+        """(sites, positions) = G(z), BatchNorm in training mode (layers.py:143-147).  Activations
+        stay in the generator workspace for a following gen_backward."""
+        o, G, Gb = self.ops, self.G.p, self.Gbuf.p
+        self.Z.copy_(z.reshape(self.B, self.latent))
+        self.g_batches_tracked += 1
+        o.gemm_nn(self.Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), self.gA[1].view(self.B, -1))
+        for i in range(1, 5):
+            n = f"twod_conv_layers.{3 * (i - 1) + 1}"
+            o.bn_fwd(self.gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"], Gb[n + ".running_var"],
+                     self.gH[i], self.gStat[i])
+            w = G[f"twod_conv_layers.{3 * i}.weight"]
+            if i < 4:
+                o.conv_up(self.gH[i], w, self.gA[i + 1])
+            else:
+                o.conv_up(self.gH[i], w, out_s, self.act_id)
+        o.convt1d_s1(self.Z, G["oned_conv_layers.0.weight"], self.hA[1])
+        for i in range(1, 5):
+            n = f"oned_conv_layers.{3 * (i - 1) + 1}"
+            o.bn_fwd(self.hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"], Gb[n + ".running_var"],
+                     self.hH[i], self.hStat[i])
+            w = G[f"oned_conv_layers.{3 * i}.weight"]
+            if i < 4:
+                o.convt1d_up(self.hH[i], w, self.hA[i + 1])
+            else:
+                o.convt1d_up(self.hH[i], w, out_p, self.act_id)
+
+    def gen_backward(self, xs, xp, dxs, dxp) -> None:
+        """Gradients of every generator parameter given d loss/d sites and d loss/d positions of the
+        batch produced by the preceding gen_forward (into self.G.g, overwritten)."""
+        o, G, dG = self.ops, self.G.p, self.G.g
+        o.act_bwd(dxs, xs, self.gdX, self.act_id)
+        up = self.gdX
+        for i in range(4, 0, -1):
+            w = G[f"twod_conv_layers.{3 * i}.weight"]
+            o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
+            o.conv_down(up, w, self.gdH[i])
+            n = f"twod_conv_layers.{3 * (i - 1) + 1}"
+            o.bn_bwd(self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
+                     dG[n + ".weight"], dG[n + ".bias"])
+            up = self.gdA[i]
+        o.gemm_tn(self.Z, self.gdA[1].view(self.B, -1), dG["twod_conv_layers.0.weight"].view(self.latent, -1))
+        o.act_bwd(dxp, xp, self.hdX, self.act_id)
+        up = self.hdX
+        for i in range(4, 0, -1):
+            w = G[f"oned_conv_layers.{3 * i}.weight"]
+            o.convt1d_wgrad(self.hH[i], up, dG[f"oned_conv_layers.{3 * i}.weight"])
+            o.convt1d_down(up, w, self.hdH[i])
+            n = f"oned_conv_layers.{3 * (i - 1) + 1}"
+            o.bn_bwd(self.hdH[i], self.hH[i], self.hA[i], self.hStat[i], G[n + ".weight"], self.hdA[i],
+                     dG[n + ".weight"], dG[n + ".bias"])
+            up = self.hdA[i]
+        o.gemm_tn(self.Z, self.hdA[1].view(self.B, -1), dG["oned_conv_layers.0.weight"].view(self.latent, -1))
+
+    # ------------------------------------------------------------------------------------------
+    # discriminator pieces
+    # ------------------------------------------------------------------------------------------
+    def _d_forward2d(self, lo: int, hi: int) -> None:
+        o = self.ops
+        for k in range(1, 5):
+            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi])
+            gw, gb = self.dgn(k)
+            o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi])
+
+    def _d_backward1(self, lo: int, hi: int, g_lo: int, g_hi: int, g_out: Optional[torch.Tensor]) -> None:
+        """First-order backward of sum_n coef[n] * score[n] through the 2-D tower for slots [lo, hi).
+        The input gradient is produced only for slots [g_lo, g_hi) (into g_out)."""
+        o = self.ops
+        o.head_seed(self.D.p["out.weight"], self.coef_cur[lo:hi], self.dU[4][lo:hi])
+        for k in range(4, 0, -1):
+            gw, _ = self.dgn(k)
+            o.gn_bwd(self.dU[k][lo:hi], self.dH[k][lo:hi], self.dA[k][lo:hi], self.dStat[k][lo:hi], gw,
+                     self.dJ[k][lo:hi], self.dStatB[k][lo:hi], self.dPG[k][lo:hi], self.dPB[k][lo:hi])
+            if k > 1:
+                o.conv_up(self.dJ[k][lo:hi], self.dconv_w(k), self.dU[k - 1][lo:hi])
+            elif g_out is not None:
+                o.conv_up(self.dJ[1][g_lo:g_hi], self.dconv_w(1), g_out)
+
+    def disc_forward(self, xs: torch.Tensor, xp: torch.Tensor, score: torch.Tensor) -> None:
+        """score = D(xs, xp) for up to 2B samples (layers.py:487-493)."""
+        n = xs.shape[0]
+        o = self.ops
+        self.X0[:n].copy_(xs)
+        self.P0[:n].copy_(xp)
+        self._d_forward2d(0, n)
+        cw, cb, gw, gb = self._d1d_params(self.D.p)
+        o.d1d_fwd(self.P0[:n], cw, cb, gw, gb, [a[:n] for a in self.d1A], self.F1[:n])
+        o.head_fwd(self.dH[4][:n], self.F1[:n], self.D.p["out.weight"], self.D.p["out.bias"], score)
+
+    # ------------------------------------------------------------------------------------------
+    # critic step
+    # ------------------------------------------------------------------------------------------
+    def critic_grads(self, real_s: torch.Tensor, real_p: torch.Tensor, z: torch.Tensor,
+                     t: Optional[torch.Tensor] = None) -> None:
+        """Loss W = mean D(fake) - mean D(real) + penalty and its gradient w.r.t. every
+        discriminator parameter (into self.D.g, overwritten); self.closs = [W, mean real, mean
+        fake, penalty].  `t` (B values in [0,1)) is the gp interpolation draw."""
+        o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
+        Dp, Dg = self.D.p, self.D.g
+        self.X0[:B].copy_(real_s)
+        self.P0[:B].copy_(real_p)
+        self.gen_forward(z, self.X0[B:2 * B], self.P0[B:2 * B])
+        if self.loss == "gp":
+            self.tbuf.copy_(t.reshape(B))
+            o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
+        # primal forward
+        self._d_forward2d(0, NS)
+        cw, cb, gw, gb = self._d1d_params(Dp)
+        o.d1d_fwd(self.P0, cw, cb, gw, gb, self.d1A, self.F1)
+        o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
+        # first-order backward (+ input gradient of the penalised samples)
+        self.coef_cur = self.coef
+        self._d_backward1(0, NS, NS - NP, NS, self.G0[:NP])
+        # penalty value and v = d penalty / d g, written as the tangent input
+        if self.loss == "gp":
+            o.gp_penalty(self.G0[:NP], self.lam, self.X0[NS:NT], self.pen)
+        else:
+            o.div_penalty(self.G0[:NP], B, self.X0[NS:NT], self.pen)
+        o.critic_loss(self.score, B, self.pen, self.closs)
+        # tangent forward of v through the 2-D tower (primal state = the penalised samples' slots)
+        pl, ph = NS - NP, NS
+        for k in range(1, 5):
+            o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT])
+            gw_k, _ = self.dgn(k)
+            o.gn_jvp(self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph], self.dStat[k][pl:ph], gw_k,
+                     self.dH[k][NS:NT], self.dStatT[k][NS:NT])
+        # second-order backward of the penalised samples
+        hbar = None
+        if self.loss == "div":
+            o.head_seed(Dp["out.weight"], self.coef_top, self.HB4)
+            hbar = self.HB4
+        for k in range(4, 0, -1):
+            gw_k, _ = self.dgn(k)
+            o.gn_bwd2(hbar, self.dU[k][pl:ph], self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph],
+                      self.dStat[k][pl:ph], self.dStatB[k][pl:ph], self.dStatT[k][NS:NT], gw_k,
+                      self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT])
+            if k > 1:
+                o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT])
+                hbar = self.dU[k - 1][NS:NT]
+        # parameter gradients: one weight-gradient pass per stage over all 4B slots
+        for k in range(1, 5):
+            o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
+            gname = f"twod_conv_layers.{3 * (k - 1) + 1}"
+            if self.loss == "gp":
+                r = (0, 2 * B, NS, NT)
+            else:
+                r = (NS, NT, 0, 0)
+            o.rows_reduce(self.dPG[k], Dg[gname + ".weight"], *r)
+            o.rows_reduce(self.dPB[k], Dg[gname + ".bias"], *r)
+        o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
+        o.head_wgrad(self.F1, self.coef_w, Dg["out.weight"].view(-1)[FEAT2:])
+        o.head_wgrad(self.ones2B, self.coef_w, Dg["out.bias"])
+        dcw, dcb, dgw, dgb = self._d1d_params(Dg)
+        o.d1d_bwd(self.P0, cw, cb, gw, gb, self.d1A, self.coef_w, Dp["out.weight"].view(-1)[FEAT2:],
+                  dcw, dcb, dgw, dgb, None)
+
+    def critic_step(self, real_s, real_p, z, t=None) -> None:
+        self.critic_grads(real_s, real_p, z, t)
+        self.adam_d()
+
+    # ------------------------------------------------------------------------------------------
+    # generator step
+    # ------------------------------------------------------------------------------------------
+    def generator_grads(self, z: torch.Tensor) -> None:
+        """loss = -mean D(G(z)) and its gradient w.r.t. the generator parameters (self.G.g);
+        self.gloss holds the loss (src/train_wgan_v2.py:619-633)."""
+        o, B = self.ops, self.B
+        Dp = self.D.p
+        self.gen_forward(z, self.gXs, self.gXp)
+        self.X0[:B].copy_(self.gXs)
+        self.P0[:B].copy_(self.gXp)
+        self._d_forward2d(0, B)
+        cw, cb, gw, gb = self._d1d_params(Dp)
+        o.d1d_fwd(self.P0[:B], cw, cb, gw, gb, [a[:B] for a in self.d1A], self.F1[:B])
+        o.head_fwd(self.dH[4][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])
+        o.neg_mean(self.score[:B], self.gloss)
+        self.coef_cur = self.coef_gen
+        self._d_backward1(0, B, 0, B, self.G0[:B])
+        o.d1d_bwd(self.P0[:B], cw, cb, gw, gb, [a[:B] for a in self.d1A], self.coef_gen,
+                  Dp["out.weight"].view(-1)[FEAT2:], None, None, None, None, self.dP0)
+        self.gen_backward(self.gXs, self.gXp, self.G0[:B], self.dP0)
+
+    def generator_step(self, z) -> None:
+        self.generator_grads(z)
+        self.adam_g()
+
+    # ------------------------------------------------------------------------------------------
+    def adam_d(self) -> None:
+        self.D.step += 1
+        self.ops.adam(self.D.flat, self.D.gflat, self.D.mflat, self.D.vflat, self.D.step, self.lr_d,
+                      self.betas[0], self.betas[1], self.eps)
+
+    def adam_g(self) -> None:
+        self.G.step += 1
+        self.ops.adam(self.G.flat, self.G.gflat, self.G.mflat, self.G.vflat, self.G.step, self.lr_g,
+                      self.betas[0], self.betas[1], self.eps)
+
+    def train_iteration(self, real_batches: List[Tuple[torch.Tensor, torch.Tensor]], zs: List[torch.Tensor],
+                        ts: Optional[List[torch.Tensor]] = None) -> None:
+        """critic_iter critic steps then one generator step (src/train_wgan_v2.py:516-634)."""
+        for h, (rs, rp) in enumerate(real_batches):
+            self.critic_step(rs, rp, zs[h], None if ts is None else ts[h])
+        self.generator_step(zs[len(real_batches)])

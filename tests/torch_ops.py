@@ -1,0 +1,269 @@
+"""Plain-torch statement of every device op the engine calls (TEST INFRASTRUCTURE).
+
+Two uses: (1) the per-kernel reference the GPU tests compare each HIP op against, on the same
+inputs; (2) a CPU backend that lets the `not gpu` tests run the engine's host logic (buffer
+layout, op order, seeds, reductions) against the autograd oracle.  The product never imports
+this file: its default and only backend is the HIP library.
+
+Every method has the signature of the same-named method of pgan_hip.HipOps and writes its
+results into caller-provided output tensors.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+SLOPE = 0.1
+EPS = 1e-5
+
+
+def _mask(h):
+    return torch.where(h > 0, torch.ones_like(h), torch.full_like(h, SLOPE))
+
+
+def _mean(x):
+    return x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
+
+
+class TorchOps:
+    name = "torch"
+
+    # ---------------- conv family: weight w[Cs, Cl, 4(,4)], small side S, large side L ----------
+    def conv_down(self, x, w, y):
+        y.copy_(F.conv2d(x, w, None, stride=2, padding=1))
+
+    def conv_up(self, y, w, x, act=0):
+        o = F.conv_transpose2d(y, w, None, stride=2, padding=1)
+        if act == 1:
+            o = torch.sigmoid(o)
+        elif act == 2:
+            o = torch.tanh(o)
+        x.copy_(o)
+
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0):
+        """dw[cs,cl,kh,kw] = sum_n sum_{oh,ow} ya[n,cs,oh,ow] * x[r(n),cl,2oh-1+kh,2ow-1+kw] where
+        r(n) = n for n < n_keep, n + n_swap for n_keep <= n < n_keep + n_swap, n - n_swap after."""
+        n = ya.shape[0]
+        if n_keep is None:
+            n_keep = n
+        idx = torch.arange(n)
+        if n_swap:
+            idx = torch.where(idx < n_keep, idx, torch.where(idx < n_keep + n_swap, idx + n_swap, idx - n_swap))
+        xr = x[idx]
+        dw.copy_(torch.nn.grad.conv2d_weight(xr, dw.shape, ya, stride=2, padding=1))
+
+    # ---------------- GroupNorm(1, C) + LeakyReLU family (per-sample statistics) ----------------
+    def gn_fwd(self, a, gamma, beta, h, stats):
+        mu = _mean(a)
+        var = _mean((a - mu) ** 2)
+        r = torch.rsqrt(var + EPS)
+        g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
+        b = beta.view(1, -1, *([1] * (a.dim() - 2)))
+        h.copy_(F.leaky_relu(g * ((a - mu) * r) + b, SLOPE))
+        stats[:, 0] = mu.flatten()
+        stats[:, 1] = r.flatten()
+
+    def _xhat(self, a, stats):
+        sh = (-1,) + (1,) * (a.dim() - 1)
+        return (a - stats[:, 0].view(sh)) * stats[:, 1].view(sh), stats[:, 1].view(sh)
+
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
+        xh, r = self._xhat(a, stats)
+        g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
+        e = _mask(h) * u
+        w = g * e
+        mw, mwx = _mean(w), _mean(w * xh)
+        d.copy_(r * (w - mw - xh * mwx))
+        stats_b[:, 0] = mw.flatten()
+        stats_b[:, 1] = mwx.flatten()
+        red = tuple(range(2, a.dim()))
+        pg.copy_((e * xh).sum(red))
+        pb.copy_(e.sum(red))
+
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
+        xh, r = self._xhat(a, stats)
+        g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
+        tb, c = _mean(t), _mean(xh * t)
+        hd.copy_(_mask(h) * g * (r * (t - tb - xh * c)))
+        stats_t[:, 0] = tb.flatten()
+        stats_t[:, 1] = c.flatten()
+
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
+        xh, r = self._xhat(a, stats)
+        sh = (-1,) + (1,) * (a.dim() - 1)
+        g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
+        m = _mask(h)
+        mw, mwx = stats_b[:, 0].view(sh), stats_b[:, 1].view(sh)
+        tb, c = stats_t[:, 0].view(sh), stats_t[:, 1].view(sh)
+        w = g * m * u
+        hb = torch.zeros_like(u) if hbar is None else hbar.view_as(u)
+        q = g * m * hb
+        mq, mqx, mwt = _mean(q), _mean(q * xh), _mean(w * t)
+        mQ = mq - r * (c * mw + mwx * tb)
+        mQx = mqx - 2 * r * c * mwx
+        mwxd = r * (mwt - mw * tb - mwx * c)
+        Q = q - r * (c * w + mwx * t)
+        p.copy_(r * (Q - mQ - xh * (mQx + mwxd)))
+        xd = r * (t - tb - xh * c)
+        red = tuple(range(2, a.dim()))
+        pg.copy_((m * u * xd + m * hb * xh).sum(red))
+        pb.copy_((m * hb).sum(red))
+
+    def rows_reduce(self, part, out, r0, r1, r2, r3, accumulate=False):
+        """out[c] (+)= sum of part[n, c] over rows [r0, r1) and [r2, r3)."""
+        v = part[r0:r1].sum(0) + part[r2:r3].sum(0)
+        if accumulate:
+            out.add_(v)
+        else:
+            out.copy_(v)
+
+    # ---------------- linear head ----------------
+    def head_fwd(self, h4, f1, w, b, score):
+        """score[n] = <w[:8192], h4[n]> + <w[8192:], f1[n]> + b."""
+        k = h4[0].numel()
+        score.copy_(h4.flatten(1) @ w.flatten()[:k] + f1.flatten(1) @ w.flatten()[k:] + b)
+
+    def head_seed(self, w, coef, u4):
+        """u4[n] = coef[n] * w[:8192]."""
+        k = u4[0].numel()
+        u4.copy_((coef.view(-1, 1) * w.flatten()[:k].view(1, -1)).view_as(u4))
+
+    def head_wgrad(self, x, coef, dw):
+        """dw[j] = sum_n coef[n] * x[n, j]."""
+        dw.copy_((coef.view(-1, 1) * x.flatten(1)).sum(0))
+
+    # ---------------- penalties ----------------
+    def interpolate(self, t, real, fake, out):
+        sh = (-1,) + (1,) * (real.dim() - 1)
+        tt = t.view(sh)
+        out.copy_(tt * real + (1 - tt) * fake)
+
+    def gp_penalty(self, g, lam, v, pen):
+        """pen = lam * mean((|g|-1)^2); v = d pen / d g."""
+        n = g.numel()
+        a = g.abs()
+        pen.copy_(((a - 1) ** 2).sum() * (lam / n))
+        v.copy_((2.0 * lam / n) * (a - 1) * torch.sign(g))
+
+    def div_penalty(self, g, nb, v, pen):
+        """g holds 2*nb samples (real then fake).  pen = mean_b(|g_real,b|^6 + |g_fake,b|^6);
+        v = d pen / d g = 6 |g_n|^4 g_n / nb."""
+        s = g.flatten(1).pow(2).sum(1)
+        pen.copy_((s ** 3).sum() / nb)
+        v.copy_((6.0 / nb) * (s ** 2).view(-1, *([1] * (g.dim() - 1))) * g)
+
+    # ---------------- discriminator 1-D tower ----------------
+    def d1d_fwd(self, xp, cw, cb, gw, gb, a_save, feat):
+        """Conv1d(k4)+bias -> GroupNorm(1,C) -> LeakyReLU, three times.  cw/cb/gw/gb are lists of 3.
+        a_save[i] receives the conv outputs (pre-norm); feat the final activations (N, 64*55)."""
+        y = xp
+        for i in range(3):
+            a = F.conv1d(y, cw[i], cb[i])
+            a_save[i].copy_(a)
+            y = F.leaky_relu(F.group_norm(a, 1, gw[i], gb[i], EPS), SLOPE)
+        feat.copy_(y.flatten(1))
+
+    def d1d_bwd(self, xp, cw, cb, gw, gb, a_save, coef, w_tail, d_cw, d_cb, d_gw, d_gb, dxp):
+        """Backward of sum_n coef[n] * <w_tail, feat[n]> through the 1-D tower: parameter gradients
+        (overwritten) and, when dxp is not None, the gradient w.r.t. the positions input."""
+        xs = xp.detach().clone().requires_grad_(dxp is not None)
+        ps = [t.detach().clone().requires_grad_(True) for t in list(cw) + list(cb) + list(gw) + list(gb)]
+        cw_, cb_, gw_, gb_ = ps[0:3], ps[3:6], ps[6:9], ps[9:12]
+        y = xs
+        for i in range(3):
+            y = F.leaky_relu(F.group_norm(F.conv1d(y, cw_[i], cb_[i]), 1, gw_[i], gb_[i], EPS), SLOPE)
+        loss = (coef.view(-1, 1) * y.flatten(1) * w_tail.view(1, -1)).sum()
+        ins = ps + ([xs] if dxp is not None else [])
+        gr = torch.autograd.grad(loss, ins)
+        if d_cw is not None:
+            for dst, src in zip(list(d_cw) + list(d_cb) + list(d_gw) + list(d_gb), gr[:12]):
+                dst.copy_(src)
+        if dxp is not None:
+            dxp.copy_(gr[12])
+
+    # ---------------- generator pieces ----------------
+    def gemm_nn(self, a, b, c):
+        """c[M,N] = a[M,K] @ b[K,N]."""
+        c.copy_(a @ b)
+
+    def gemm_tn(self, a, b, c):
+        """c[M,N] = a[K,M]^T @ b[K,N]."""
+        c.copy_(a.t() @ b)
+
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
+        """Training-mode BatchNorm + LeakyReLU.  stats[0,c]=batch mean, stats[1,c]=rstd.  Running
+        stats are updated in place (momentum, unbiased variance)."""
+        red = (0,) + tuple(range(2, a.dim()))
+        sh = (1, -1) + (1,) * (a.dim() - 2)
+        n = a.numel() // a.shape[1]
+        mu = a.mean(red)
+        var = ((a - mu.view(sh)) ** 2).mean(red)
+        r = torch.rsqrt(var + EPS)
+        h.copy_(F.leaky_relu(gamma.view(sh) * ((a - mu.view(sh)) * r.view(sh)) + beta.view(sh), SLOPE))
+        stats[0] = mu
+        stats[1] = r
+        rmean.mul_(1 - momentum).add_(momentum * mu)
+        rvar.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
+
+    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
+        red = (0,) + tuple(range(2, a.dim()))
+        sh = (1, -1) + (1,) * (a.dim() - 2)
+        n = a.numel() // a.shape[1]
+        xh = (a - stats[0].view(sh)) * stats[1].view(sh)
+        dy = _mask(h) * dh
+        sg = (dy * xh).sum(red)
+        sb = dy.sum(red)
+        dgamma.copy_(sg)
+        dbeta.copy_(sb)
+        da.copy_(gamma.view(sh) * stats[1].view(sh) * (dy - sb.view(sh) / n - xh * sg.view(sh) / n))
+
+    def act_bwd(self, dy, y, dx, act):
+        """dx = dy * act'(pre) expressed through the activation's output y (1 sigmoid, 2 tanh)."""
+        if act == 1:
+            dx.copy_(dy * y * (1 - y))
+        else:
+            dx.copy_(dy * (1 - y * y))
+
+    def convt1d_s1(self, z, w, y):
+        """First 1-D generator layer: ConvTranspose1d(k4, s1, p0) on a length-1 input =
+        y[b, co, k] = sum_ci z[b, ci] w[ci, co, k]."""
+        y.copy_(F.conv_transpose1d(z.view(z.shape[0], -1, 1), w))
+
+    def convt1d_up(self, y, w, x, act=0):
+        o = F.conv_transpose1d(y, w, None, stride=2, padding=1)
+        if act == 1:
+            o = torch.sigmoid(o)
+        elif act == 2:
+            o = torch.tanh(o)
+        x.copy_(o)
+
+    def convt1d_down(self, x, w, y):
+        """Input gradient of convt1d_up: y[n,cs,o] = sum_{cl,k} x[n,cl,2o-1+k] w[cs,cl,k]."""
+        y.copy_(F.conv1d(x, w, None, stride=2, padding=1))
+
+    def convt1d_wgrad(self, ya, x, dw):
+        dw.copy_(torch.nn.grad.conv1d_weight(x, dw.shape, ya, stride=2, padding=1))
+
+    # ---------------- optimiser / misc ----------------
+    def adam(self, p, g, m, v, step, lr, b1, b2, eps):
+        bc1 = 1.0 - b1 ** step
+        bc2 = 1.0 - b2 ** step
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+    def affine(self, x, scale, shift, out):
+        out.copy_(x * scale + shift)
+
+    def critic_loss(self, score, nb, pen, out):
+        """out = [W, mean_real, mean_fake, pen] with W = mean(score[nb:2nb]) - mean(score[:nb]) + pen."""
+        mr, mf = score[:nb].mean(), score[nb:2 * nb].mean()
+        out[0] = mf - mr + pen.reshape(())
+        out[1] = mr
+        out[2] = mf
+        out[3] = pen.reshape(())
+
+    def neg_mean(self, score, out):
+        out.copy_(-score.mean())
