@@ -1,0 +1,129 @@
+/* C-ABI of libpgan_hip.so: hand-written gfx950 (MI355X) kernels for the DCWGAN-GP training step of
+ * PG-Alignments-GAN.
+ *
+ * Conventions for every entry point: plain device pointers and sizes, fp32 tensors contiguous in
+ * NCHW / NCL order, work is only ENQUEUED on the caller's hipStream_t (no synchronisation, no
+ * allocation, no host reads), scratch comes from the caller, return 0 on success, -1 for an
+ * unsupported shape or argument (nothing was launched), -2 if HIP reported a launch error.
+ *
+ * The reference has no native boundary (it is pure PyTorch); each entry point replaces the ATen
+ * op(s) that the cited reference line dispatches to.  Paths are relative to /root/reference.
+ */
+#ifndef PGAN_HIP_H
+#define PGAN_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- k=4, stride=2, pad=1 convolution pair, weight W[Cs][Cl][4][4] between a small side
+ * S[N][Cs][hs][hs] and a large side L[N][Cl][2hs][2hs].  Cl > 1: fp32 MFMA implicit GEMM
+ * (Cs % 64 == 0, Cl % 64 == 0 for up / % 8 for down and wgrad, hs in {4, 8, 16}); Cl == 1: hs == 32, Cs <= 64. */
+
+/* S = conv2d(L, W, stride 2, pad 1): nn.Conv2d forward, src/layers.py:441-463 (discriminator);
+ * input-gradient of nn.ConvTranspose2d, src/layers.py:97-112 (generator backward). */
+int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
+
+/* L = conv_transpose2d(S, W, stride 2, pad 1): nn.ConvTranspose2d forward, src/layers.py:97-112, with
+ * the trailing nn.Sigmoid (:114) / nn.Tanh (:255) fused when act = 1 / 2 (Cl == 1 only);
+ * input-gradient of nn.Conv2d (autograd through src/layers.py:441-463, src/train_wgan_v2.py:58-60,609). */
+int pgan_conv_up(const float* S, const float* W, float* L, int N, int Cs, int Cl, int hs, int act, hipStream_t st);
+
+/* dW = sum_n S[n] (x) L[r(n)] (weight gradient of both of the above; aten::convolution_backward
+ * reached from src/train_wgan_v2.py:609,633).  r(n) = n for n < n_keep, n + n_swap for
+ * n < n_keep + n_swap, n - n_swap otherwise (pairs the engine's adjoint slots with its activation
+ * slots).  ws: scratch of pgan_conv_wgrad_workspace_floats(...) floats. */
+long long pgan_conv_wgrad_workspace_floats(int N, int Cs, int Cl, int hs);
+int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+                    int hs, int n_keep, int n_swap, hipStream_t st);
+
+/* out[c] (+)= sum of part[r * ld + c] over rows [r0,r1) and [r2,r3), c < C <= ld: finishes the
+ * per-sample partial sums of the norm-parameter and 1-D-tower gradients. */
+int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r1, int r2, int r3, int accumulate,
+                     hipStream_t st);
+
+/* ---- GroupNorm(1,C) + LeakyReLU(0.1), per-sample statistics (src/layers.py:442-443 and the three
+ * repeats below it).  a, h, u, d, t, hd, hbar, p: [N][C][HW]; stats*: [N][2]; pg, pb: [N][C].
+ * C <= 512, HW a power of two >= 16, C*HW % 4096 == 0. */
+int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C, int HW,
+                hipStream_t st);
+/* first-order backward (autograd through GroupNorm/LeakyReLU): d = dL/da from u = dL/dh;
+ * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta. */
+int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
+                float* stats_b, float* pg, float* pb, int N, int C, int HW, hipStream_t st);
+/* tangent (JVP) of the same block: hd from the tangent t of a; stats_t = (mean t, mean xhat*t). */
+int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
+                float* stats_t, int N, int C, int HW, hipStream_t st);
+/* second-order backward: the piece of autograd's double backward (create_graph=True at
+ * src/layers.py:51-53,66-74) that belongs to this block.  hbar may be NULL (= 0). */
+int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
+                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int N,
+                 int C, int HW, hipStream_t st);
+
+/* ---- BatchNorm (training mode) + LeakyReLU(0.1), src/layers.py:93-110,119-135.  a, h: [B][C][HW],
+ * HW % 4 == 0; stats: [2][C] = batch mean, rstd; running stats updated in place (unbiased variance). */
+int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
+                float* stats, int B, int C, int HW, float momentum, hipStream_t st);
+int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
+                float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st);
+
+/* ---- linear head nn.Linear(11712, 1) over cat(2-D features, 1-D features), src/layers.py:482,491-493 */
+int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float* b, float* score, int N, int K2, int K1,
+                  hipStream_t st);
+int pgan_head_seed(const float* w, const float* coef, float* u4, int N, int K, hipStream_t st); /* u4[n] = coef[n] w */
+int pgan_head_wgrad(const float* x, const float* coef, float* dw, int N, int J, hipStream_t st); /* dw = sum coef[n] x[n] */
+
+/* ---- penalties.  pgan_interpolate: src/layers.py:38-41; pgan_gp_penalty: value of src/layers.py:54
+ * (elementwise |g|, mean over all elements, times lambda) and v = d penalty / d g; pgan_div_penalty:
+ * value of src/layers.py:69-77 (per-sample |g|^6 of real then fake, g: [2 nb][M]) and its v. */
+int pgan_interpolate(const float* t, const float* real, const float* fake, float* out, int B, int M, hipStream_t st);
+int pgan_gp_penalty(const float* g, float* v, float* pen, float* ws /* >= 256 floats */, long long n, float lam,
+                    hipStream_t st);
+int pgan_div_penalty(const float* g, float* v, float* pen, float* ws /* >= 2 nb floats */, int nb, int M,
+                     hipStream_t st);
+/* out = [W, mean real, mean fake, pen], W = mean(score[nb:2nb]) - mean(score[:nb]) + pen
+ * (src/train_wgan_v2.py:584-587,594-597). */
+int pgan_critic_loss(const float* score, const float* pen, float* out, int nb, hipStream_t st);
+int pgan_sum_scale(const float* x, float* out, int n, float scale, hipStream_t st); /* out[0] = scale * sum x */
+
+/* derivative of the generator's output activation through its output y (1 sigmoid, 2 tanh) */
+int pgan_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, hipStream_t st);
+/* out = x * scale + shift: torchvision Normalize(0.5, 0.5) of src/train_wgan_v2.py:453,519-521 */
+int pgan_affine(const float* x, float* out, long long n, float scale, float shift, hipStream_t st);
+
+/* torch.optim.Adam step (src/train_wgan_v2.py:489-490,612,634) over one flat, 4-float-padded buffer.
+ * step_dev != NULL: device-resident step counter, incremented then used (graph replay advances it). */
+int pgan_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+              int* step_dev, int step, hipStream_t st);
+
+/* Philox4x32-10 draws replacing torch.randn (src/train_wgan_v2.py:534,621) and np.random.random
+ * (src/layers.py:37).  state: 4 uint32 on the device (seed lo, hi, offset lo, hi), advanced by the call. */
+int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStream_t st);
+
+/* ---- discriminator 1-D tower, src/layers.py:470-480.  params: 12 device pointers
+ * (conv w, conv b, gn w, gn b) x 3.  a1 [N][16][61], a2 [N][32][58], a3 [N][64][55] keep the conv
+ * outputs for the backward; feat [N][3520]. */
+int pgan_d1d_fwd(const float* xp, const float* const* params, float* a1, float* a2, float* a3, float* feat, int N,
+                 hipStream_t st);
+/* backward of sum_n coef[n] <w_tail, feat[n]>: per-sample parameter-gradient rows part[N][part_ld]
+ * (tensor i at offs[i], may be NULL) and dxp [N][1][64] (may be NULL). */
+int pgan_d1d_bwd(const float* xp, const float* const* params, const float* a1, const float* a2, const float* a3,
+                 const float* coef, const float* w_tail, float* part, int part_ld, const int* offs, float* dxp, int N,
+                 hipStream_t st);
+
+/* ---- generator 1-D tower stages nn.ConvTranspose1d(k4, s2, p1), src/layers.py:122-137: forward
+ * (+ fused sigmoid/tanh), input gradient, weight gradient.  y [N][Cs][Ls], x [N][Cl][2 Ls], w [Cs][Cl][4]. */
+int pgan_ct1d_up(const float* y, const float* w, float* x, int N, int Cs, int Cl, int Ls, int act, hipStream_t st);
+int pgan_ct1d_down(const float* x, const float* w, float* y, int N, int Cs, int Cl, int Ls, hipStream_t st);
+int pgan_ct1d_wgrad(const float* ya, const float* x, float* dw, int N, int Cs, int Cl, int Ls, hipStream_t st);
+
+/* ---- C[M][N] = A[M][K] B[K][N] (transa 0) or A[K][M]^T B[K][N] (transa 1): the generator's first
+ * ConvTranspose layers on a 1x1 / length-1 input (src/layers.py:92,117) and their weight gradients. */
+int pgan_gemm(const float* A, const float* B, float* C, int M, int N, int K, int transa, hipStream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGAN_HIP_H */

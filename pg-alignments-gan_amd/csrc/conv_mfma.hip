@@ -1,0 +1,736 @@
+// fp32 MFMA implicit-GEMM kernels for the k=4, stride=2, pad=1 convolution pair that carries
+// 98 % of the DCWGAN-GP step's FLOPs (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// One weight tensor W[Cs][Cl][4][4] links a SMALL side S[n][Cs][H][H] and a LARGE side
+// L[n][Cl][2H][2H]:
+//   DOWN  (L -> S)  S[cs][oh][ow] = sum_{cl,kh,kw} L[cl][2oh-1+kh][2ow-1+kw] W[cs][cl][kh][kw]
+//                   = Conv2d fprop of the discriminator  (reference src/layers.py:441-463)
+//                   = ConvTranspose2d input-gradient of the generator (src/layers.py:97-112)
+//   UP    (S -> L)  L[cl][ih][iw] = sum_{cs,kh,kw : ih = 2oh-1+kh} S[cs][oh][ow] W[cs][cl][kh][kw]
+//                   = Conv2d input-gradient of the discriminator = ConvTranspose2d fprop of the generator
+//   WGRAD           dW[cs][cl][kh][kw] = sum_{n,oh,ow} S[n][cs][oh][ow] L[r(n)][cl][2oh-1+kh][2ow-1+kw]
+// All tensors fp32, NCHW contiguous.  MFMA operand maps (32x32x2): lane l supplies
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of lane l is
+// D[i = (r&3) + 8(r>>2) + 4(l>>5)][j = l&31].
+#include "pgan_common.h"
+
+namespace {
+
+// A tile of BN consecutive S-side pixels in (n, oh, ow) order: either R rows of one sample or
+// SEG whole samples.
+template <int HS, int BN>
+struct PixTile {
+    static constexpr int WS = HS, PIX = HS * HS;
+    static constexpr int SEG = (BN >= PIX) ? BN / PIX : 1;
+    static constexpr int R = (BN >= PIX) ? HS : BN / WS;
+    static constexpr int TPS = (BN >= PIX) ? 1 : PIX / BN;
+    static_assert(BN % WS == 0, "tile must hold whole rows");
+    static_assert((BN >= PIX) ? (BN % PIX == 0) : (PIX % BN == 0), "tile/sample mismatch");
+    __host__ __device__ static int ntiles(int N) { return (BN >= PIX) ? (N + SEG - 1) / SEG : N * TPS; }
+    __device__ static void origin(int tile, int& n0, int& oh0) {
+        if (BN >= PIX) { n0 = tile * SEG; oh0 = 0; }
+        else { n0 = tile / TPS; oh0 = (tile % TPS) * R; }
+    }
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+    // logical tiles so tiles that share an operand panel hit the same L2.  Speed only.
+    return (total % 8 == 0) ? (b % 8) * (total / 8) + b / 8 : b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DOWN: GEMM M = Cs (BM per block), N = pixels (BN per block), K = Cl*16 (CLC channels per step)
+// ------------------------------------------------------------------------------------------------
+template <int HS, int BM, int BN, int CLC>
+__global__ __launch_bounds__(256) void conv_down_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        float* __restrict__ Y, int N, int Cs, int Cl) {
+    using T = PixTile<HS, BN>;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
+    constexpr int SEG = T::SEG, R = T::R;
+    constexpr int PR = 2 * R + 2, PC = 2 * WS + 2, PCP = 3 * WS;
+    constexpr int CHS = SEG * PR * PCP;
+    constexpr int ALD = CLC * 16 + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
+    constexpr int AV = BM * CLC * 4 / 256;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && AV >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[BM * ALD + CLC * CHS];
+    float* As = lds;
+    float* Bs = lds + BM * ALD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nmt = Cs / BM, npt = T::ntiles(N);
+    const int b = xcd_remap(blockIdx.x, nmt * npt);
+    const int ptile = b / nmt, cs0 = (b % nmt) * BM;
+    int n0, oh0;
+    T::origin(ptile, n0, oh0);
+
+    // per-thread patch elements (same geometry for every channel)
+    int64_t poff[NQ];
+    int loff[NQ];
+    bool pval[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        const int seg = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+        const int n = n0 + seg, ih = 2 * oh0 - 1 + pr, iw = pc - 1;
+        pval[q] = (e < PE) && n < N && ih >= 0 && ih < HL && iw >= 0 && iw < WL;
+        poff[q] = ((int64_t)n * Cl * HL + ih) * WL + iw;
+        loff[q] = (e < PE) ? (seg * PR + pr) * PCP + pc : -1;
+    }
+    f32x4 areg[AV];
+    float breg[CLC][NQ];
+    auto gload = [&](int cl0) {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, row = idx / (CLC * 4), c4 = idx % (CLC * 4);
+            areg[q] = *reinterpret_cast<const f32x4*>(W + ((int64_t)(cs0 + row) * Cl + cl0) * 16 + c4 * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < CLC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                breg[c][q] = pval[q] ? X[poff[q] + (int64_t)(cl0 + c) * HL * WL] : 0.f;
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, row = idx / (CLC * 4), c4 = idx % (CLC * 4);
+            *reinterpret_cast<f32x4*>(As + row * ALD + c4 * 4) = areg[q];
+        }
+#pragma unroll
+        for (int c = 0; c < CLC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (loff[q] >= 0) Bs[c * CHS + loff[q]] = breg[c][q];
+    };
+
+    int abase[TM], bbase[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = (wm * (BM / 2) + tm * 32 + j) * ALD + h * 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
+        bbase[tn] = (seg * PR + 2 * ohl + h) * PCP + 2 * ow;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nk = Cl / CLC;
+    gload(0);
+    for (int kc = 0; kc < nk; ++kc) {
+        lstore();
+        __syncthreads();
+        if (kc + 1 < nk) gload((kc + 1) * CLC);
+#pragma unroll
+        for (int c = 0; c < CLC; ++c)
+#pragma unroll
+            for (int khp = 0; khp < 2; ++khp) {
+                f32x4 a[TM];
+                float2 b0[TN], b1[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    a[tm] = *reinterpret_cast<const f32x4*>(As + abase[tm] + c * 16 + khp * 8);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float* p = Bs + c * CHS + bbase[tn] + khp * 2 * PCP;
+                    b0[tn] = *reinterpret_cast<const float2*>(p);
+                    b1[tn] = *reinterpret_cast<const float2*>(p + 2);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][0], b0[tn].x, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][1], b0[tn].y, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][2], b1[tn].x, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][3], b1[tn].y, acc[tm][tn], 0, 0, 0);
+                    }
+            }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
+        const int n = n0 + seg;
+        if (n >= N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y[(((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow] = acc[tm][tn][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UP: four sub-pixel phases, each a GEMM M = Cl (BM), N = S-grid pixels (BN), K = Cs*4.
+// Tap kh feeds output-row phase PH[kh] from S row a + DH[kh]:  kh 0:(1,+1) 1:(0,0) 2:(1,0) 3:(0,-1).
+// ------------------------------------------------------------------------------------------------
+template <int HS, int BM, int BN, int CSC>
+__global__ __launch_bounds__(256) void conv_up_kernel(const float* __restrict__ Y, const float* __restrict__ W,
+                                                      float* __restrict__ X, int N, int Cs, int Cl) {
+    using T = PixTile<HS, BN>;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
+    constexpr int SEG = T::SEG, R = T::R;
+    constexpr int PR = R + 2, PC = WS + 2, PCP = PC | 1;
+    constexpr int CHS = SEG * PR * PCP;
+    constexpr int ALD = BM + 1;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
+    constexpr int AV = CSC * BM * 4 / 256;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && CSC % 2 == 0 && AV >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[CSC * 16 * ALD + CSC * CHS];
+    float* As = lds;
+    float* Bs = lds + CSC * 16 * ALD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nmt = Cl / BM, npt = T::ntiles(N);
+    const int b = xcd_remap(blockIdx.x, nmt * npt);
+    const int ptile = b / nmt, cl0 = (b % nmt) * BM;
+    int n0, oh0;
+    T::origin(ptile, n0, oh0);
+
+    int64_t poff[NQ];
+    int loff[NQ];
+    bool pval[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        const int seg = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+        const int n = n0 + seg, a = oh0 - 1 + pr, bb = pc - 1;
+        pval[q] = (e < PE) && n < N && a >= 0 && a < HS && bb >= 0 && bb < WS;
+        poff[q] = ((int64_t)n * Cs * HS + a) * WS + bb;
+        loff[q] = (e < PE) ? (seg * PR + pr) * PCP + pc : -1;
+    }
+    f32x4 areg[AV];
+    float breg[CSC][NQ];
+    auto gload = [&](int cs0) {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, csl = idx / (BM * 4), rem = idx % (BM * 4);
+            areg[q] = *reinterpret_cast<const f32x4*>(W + ((int64_t)(cs0 + csl) * Cl + cl0) * 16 + rem * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < CSC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                breg[c][q] = pval[q] ? Y[poff[q] + (int64_t)(cs0 + c) * HS * WS] : 0.f;
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, csl = idx / (BM * 4), rem = idx % (BM * 4);
+            const int cll = rem / 4, t4 = rem % 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(csl * 16 + t4 * 4 + e) * ALD + cll] = areg[q][e];
+        }
+#pragma unroll
+        for (int c = 0; c < CSC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (loff[q] >= 0) Bs[c * CHS + loff[q]] = breg[c][q];
+    };
+
+    int abase[TM], bbase[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = wm * (BM / 2) + tm * 32 + j;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), al = rem / WS, bl = rem % WS;
+        bbase[tn] = (seg * PR + al + 1) * PCP + bl + 1;
+    }
+    f32x16 acc[TM][TN][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][p][r] = 0.f;
+
+    const int nk = Cs / CSC;
+    gload(0);
+    for (int kc = 0; kc < nk; ++kc) {
+        lstore();
+        __syncthreads();
+        if (kc + 1 < nk) gload((kc + 1) * CSC);
+#pragma unroll
+        for (int g = 0; g < CSC / 2; ++g) {
+            const int csl = 2 * g + h;
+            float a[TM][16], bv[TN][3][3];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a[tm][t] = As[(csl * 16 + t) * ALD + abase[tm]];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw)
+                        bv[tn][dh][dw] = Bs[csl * CHS + bbase[tn] + (dh - 1) * PCP + (dw - 1)];
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ph = (kh == 0 || kh == 2) ? 1 : 0, dh = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
+                    const int pw = (kw == 0 || kw == 2) ? 1 : 0, dw = (kw == 0) ? 2 : (kw == 3 ? 0 : 1);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn][ph * 2 + pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a[tm][kh * 4 + kw], bv[tn][dh][dw], acc[tm][tn][ph * 2 + pw], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), al = rem / WS, bl = rem % WS;
+        const int n = n0 + seg;
+        if (n >= N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = cl0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float* o = X + (((int64_t)n * Cl + cl) * HL + 2 * (oh0 + al)) * WL + 2 * bl;
+                *reinterpret_cast<float2*>(o) = make_float2(acc[tm][tn][0][r], acc[tm][tn][1][r]);
+                *reinterpret_cast<float2*>(o + WL) = make_float2(acc[tm][tn][2][r], acc[tm][tn][3][r]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// WGRAD: GEMM M = Cs (BM), N = (cl, tap) (16*CLB), K = pixels (PIXC per step), split over blockIdx.y.
+// Each block writes its partial into slab[blockIdx.y]; wgrad_reduce sums the slabs.
+// ------------------------------------------------------------------------------------------------
+template <int HS, int BM, int CLB, int PIXC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ YA, const float* __restrict__ X,
+                                                         float* __restrict__ slab, int N, int Cs, int Cl, int n_keep,
+                                                         int n_swap, int chunks_per_block) {
+    using T = PixTile<HS, PIXC>;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
+    constexpr int SEG = T::SEG, R = T::R;
+    constexpr int PR = 2 * R + 2, PC = 2 * WS + 2, PCP = PC + 2;               // PCP = 4 (mod 8)
+    constexpr int CHS = ((SEG * PR * PCP - 16 + 31) / 32) * 32 + 16;           // = 16 (mod 32)
+    constexpr int ALD = PIXC + 2;
+    constexpr int BN = 16 * CLB, TM = BM / 64, TN = BN / 64;
+    constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
+    constexpr int AV = BM * PIXC / 4 / 256;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && PIXC % 4 == 0 && AV >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[BM * ALD + CLB * CHS];
+    float* As = lds;
+    float* Bs = lds + BM * ALD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nct = Cl / CLB;
+    const int cs0 = (blockIdx.x / nct) * BM, cl0 = (blockIdx.x % nct) * CLB;
+    const int total_chunks = T::ntiles(N);
+    const int c_begin = blockIdx.y * chunks_per_block;
+    const int c_end = min(total_chunks, c_begin + chunks_per_block);
+
+    // chunk-invariant parts of the staging indices
+    int a_row[AV], a_seg[AV], a_in[AV];
+#pragma unroll
+    for (int q = 0; q < AV; ++q) {
+        const int idx = tid + 256 * q, row = idx / (PIXC / 4), p = (idx % (PIXC / 4)) * 4;
+        a_row[q] = row;
+        a_seg[q] = p / (R * WS);
+        a_in[q] = p % (R * WS);   // = ohl * WS + ow, 4 pixels in one row
+    }
+    int b_seg[NQ], b_pr[NQ], b_pc[NQ], loff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        b_seg[q] = e / (PR * PC);
+        const int rem = e % (PR * PC);
+        b_pr[q] = rem / PC;
+        b_pc[q] = rem % PC;
+        loff[q] = (e < PE) ? (b_seg[q] * PR + b_pr[q]) * PCP + b_pc[q] : -1;
+    }
+    f32x4 areg[AV];
+    float breg[CLB][NQ];
+    auto gload = [&](int chunk) {
+        int n0, oh0;
+        T::origin(chunk, n0, oh0);
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int n = n0 + a_seg[q];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < N)
+                v = *reinterpret_cast<const f32x4*>(YA + (((int64_t)n * Cs + cs0 + a_row[q]) * HS + oh0) * WS + a_in[q]);
+            areg[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = n0 + b_seg[q];
+            const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
+            const int ih = 2 * oh0 - 1 + b_pr[q], iw = b_pc[q] - 1;
+            const bool ok = loff[q] >= 0 && n < N && ih >= 0 && ih < HL && iw >= 0 && iw < WL;
+            const float* src = X + (((int64_t)rn * Cl + cl0) * HL + ih) * WL + iw;
+#pragma unroll
+            for (int c = 0; c < CLB; ++c) breg[c][q] = ok ? src[(int64_t)c * HL * WL] : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, p = (idx % (PIXC / 4)) * 4;
+            float* d = As + a_row[q] * ALD + p;
+            *reinterpret_cast<float2*>(d) = make_float2(areg[q][0], areg[q][1]);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(areg[q][2], areg[q][3]);
+        }
+#pragma unroll
+        for (int c = 0; c < CLB; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (loff[q] >= 0) Bs[c * CHS + loff[q]] = breg[c][q];
+    };
+
+    int abase[TM], bbase[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = (wm * (BM / 2) + tm * 32 + j) * ALD + 2 * h;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+        bbase[tn] = (wn * (CLB / 2) + tn * 2 + (j >> 4)) * CHS + ((j >> 2) & 3) * PCP + (j & 3) + 4 * h;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (c_begin < c_end) gload(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lstore();
+        __syncthreads();
+        if (ch + 1 < c_end) gload(ch + 1);
+#pragma unroll
+        for (int q = 0; q < PIXC / 4; ++q) {
+            const int p4 = 4 * q;  // compile-time after unrolling
+            const int pofs = ((p4 / (R * WS)) * PR + 2 * ((p4 % (R * WS)) / WS)) * PCP + 2 * (p4 % WS);
+            float2 a[TM];
+            float b0[TN], b1[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = *reinterpret_cast<const float2*>(As + abase[tm] + p4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                b0[tn] = Bs[bbase[tn] + pofs];
+                b1[tn] = Bs[bbase[tn] + pofs + 2];
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].x, b0[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm].y, b1[tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    float* out = slab + (int64_t)blockIdx.y * Cs * Cl * 16;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int cl = cl0 + wn * (CLB / 2) + tn * 2 + (j >> 4);
+                out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = acc[tm][tn][r];
+            }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len) {
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= len) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + z * len + i4 * 4);
+    *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cl == 1 stages (first discriminator conv / last generator conv-transpose): bandwidth-bound.
+// ------------------------------------------------------------------------------------------------
+// DOWN, Cl = 1: block = one sample x 8 output rows (256 pixels); thread = pixel, loops over cs.
+template <int HS>
+__global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                           float* __restrict__ Y, int N, int Cs) {
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 256 / WS;   // rows per block
+    constexpr int PR = 2 * RT + 2, PC = 2 * WS + 2;
+    __shared__ __attribute__((aligned(16))) float ws[64 * 16];
+    __shared__ float xs[PR * PC];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / (HS / RT), oh0 = (blockIdx.x % (HS / RT)) * RT;
+    for (int i = tid; i < Cs * 16; i += 256) ws[i] = W[i];
+    const float* xn = X + (int64_t)n * HL * WL;
+    for (int e = tid; e < PR * PC; e += 256) {
+        const int pr = e / PC, pc = e % PC, ih = 2 * oh0 - 1 + pr, iw = pc - 1;
+        xs[e] = (ih >= 0 && ih < HL && iw >= 0 && iw < WL) ? xn[ih * WL + iw] : 0.f;
+    }
+    __syncthreads();
+    const int ohl = tid / WS, ow = tid % WS;
+    float x[16];
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) x[kh * 4 + kw] = xs[(2 * ohl + kh) * PC + 2 * ow + kw];
+    float* yn = Y + ((int64_t)n * Cs * HS + oh0 + ohl) * WS + ow;
+    for (int cs = 0; cs < Cs; ++cs) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s = fmaf(x[t], ws[cs * 16 + t], s);
+        yn[(int64_t)cs * HS * WS] = s;
+    }
+}
+
+// UP, Cl = 1 (+ optional sigmoid / tanh): block = one sample x 8 S rows; thread = S pixel -> 2x2 outputs.
+template <int HS>
+__global__ __launch_bounds__(256) void conv_up_c1_kernel(const float* __restrict__ Y, const float* __restrict__ W,
+                                                         float* __restrict__ X, int N, int Cs, int act) {
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 256 / WS, CSC = 16;
+    constexpr int PR = RT + 2, PC = WS + 2, PCP = PC | 1;
+    __shared__ __attribute__((aligned(16))) float ws[64 * 16];
+    __shared__ float ys[CSC * PR * PCP];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / (HS / RT), a0 = (blockIdx.x % (HS / RT)) * RT;
+    for (int i = tid; i < Cs * 16; i += 256) ws[i] = W[i];
+    const int al = tid / WS, bl = tid % WS;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Cs; c0 += CSC) {
+        __syncthreads();
+        for (int e = tid; e < CSC * PR * PC; e += 256) {
+            const int c = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+            const int a = a0 - 1 + pr, b = pc - 1;
+            ys[(c * PR + pr) * PCP + pc] = (a >= 0 && a < HS && b >= 0 && b < WS)
+                                               ? Y[(((int64_t)n * Cs + c0 + c) * HS + a) * WS + b] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < CSC; ++c) {
+            float v[3][3];
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) v[dh][dw] = ys[(c * PR + al + dh) * PCP + bl + dw];
+            const float* w = ws + (c0 + c) * 16;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ph = (kh == 0 || kh == 2) ? 1 : 0, dh = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
+                    const int pw = (kw == 0 || kw == 2) ? 1 : 0, dw = (kw == 0) ? 2 : (kw == 3 ? 0 : 1);
+                    acc[ph * 2 + pw] = fmaf(v[dh][dw], w[kh * 4 + kw], acc[ph * 2 + pw]);
+                }
+        }
+    }
+    if (act == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = 1.f / (1.f + expf(-acc[p]));
+    } else if (act == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = tanhf(acc[p]);
+    }
+    float* o = X + ((int64_t)n * HL + 2 * (a0 + al)) * WL + 2 * bl;
+    *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[1]);
+    *reinterpret_cast<float2*>(o + WL) = make_float2(acc[2], acc[3]);
+}
+
+// WGRAD, Cl = 1: block = (sample, group of 16 cs); wave = 4 cs; lanes sweep the sample's pixels.
+// Writes per-sample partials part[n][cs*16 + tap]; a row reduction finishes the sum.
+template <int HS>
+__global__ __launch_bounds__(256) void conv_wgrad_c1_kernel(const float* __restrict__ YA, const float* __restrict__ X,
+                                                            float* __restrict__ part, int N, int Cs, int n_keep, int n_swap) {
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, PC = WL + 2, PCP = PC | 1;
+    __shared__ float xs[(HL + 2) * PCP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ngrp = Cs / 16;
+    const int n = blockIdx.x / ngrp, cs0 = (blockIdx.x % ngrp) * 16 + wave * 4;
+    const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
+    const float* xn = X + (int64_t)rn * HL * WL;
+    for (int e = tid; e < (HL + 2) * PC; e += 256) {
+        const int pr = e / PC, pc = e % PC, ih = pr - 1, iw = pc - 1;
+        xs[pr * PCP + pc] = (ih >= 0 && ih < HL && iw >= 0 && iw < WL) ? xn[ih * WL + iw] : 0.f;
+    }
+    __syncthreads();
+    float acc[4][16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[c][t] = 0.f;
+    const float* ya = YA + ((int64_t)n * Cs + cs0) * HS * WS;
+    for (int p = lane; p < HS * WS; p += 64) {
+        const int oh = p / WS, ow = p % WS;
+        float x[16];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) x[kh * 4 + kw] = xs[(2 * oh + kh) * PCP + 2 * ow + kw];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y = ya[c * HS * WS + p];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[c][t] = fmaf(y, x[t], acc[c][t]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float s = wave_sum(acc[c][t]);
+            if (lane == 0) part[(int64_t)n * Cs * 16 + (cs0 + c) * 16 + t] = s;
+        }
+}
+
+__global__ void rows_sum_kernel(const float* __restrict__ part, int ld, float* __restrict__ out, int C, int r0, int r1,
+                                int r2, int r3, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += part[(int64_t)r * ld + c];
+    for (int r = r2; r < r3; ++r) s += part[(int64_t)r * ld + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+template <int HS>
+int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl, hipStream_t st) {
+    constexpr int BM = 64, BN = 64, CLC = 8;
+    if (Cs % BM || Cl % CLC) return PGAN_EINVAL;
+    const int grid = (Cs / BM) * PixTile<HS, BN>::ntiles(N);
+    conv_down_kernel<HS, BM, BN, CLC><<<grid, 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+    return pgan_launch_status();
+}
+template <int HS>
+int launch_up(const float* Y, const float* W, float* X, int N, int Cs, int Cl, hipStream_t st) {
+    constexpr int BM = 64, BN = 64, CSC = 8;
+    if (Cl % BM || Cs % CSC) return PGAN_EINVAL;
+    const int grid = (Cl / BM) * PixTile<HS, BN>::ntiles(N);
+    conv_up_kernel<HS, BM, BN, CSC><<<grid, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
+    return pgan_launch_status();
+}
+constexpr int WG_BM = 64, WG_CLB = 8, WG_PIXC = 64;
+template <int HS>
+int wgrad_splits(int N, int Cs, int Cl) {
+    const int tiles = (Cs / WG_BM) * (Cl / WG_CLB);
+    const int chunks = PixTile<HS, WG_PIXC>::ntiles(N);
+    int want = (1024 + tiles - 1) / tiles;       // aim at ~4 blocks per CU
+    if (want > chunks) want = chunks;
+    if (want < 1) want = 1;
+    const int cpb = (chunks + want - 1) / want;
+    return (chunks + cpb - 1) / cpb;
+}
+template <int HS>
+int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
+                 int n_keep, int n_swap, hipStream_t st) {
+    if (Cs % WG_BM || Cl % WG_CLB) return PGAN_EINVAL;
+    const int chunks = PixTile<HS, WG_PIXC>::ntiles(N);
+    const int ns = wgrad_splits<HS>(N, Cs, Cl);
+    const int cpb = (chunks + ns - 1) / ns;
+    const int64_t len = (int64_t)Cs * Cl * 16;
+    if (ns * len > ws_floats) return PGAN_EINVAL;
+    dim3 grid((Cs / WG_BM) * (Cl / WG_CLB), ns);
+    conv_wgrad_kernel<HS, WG_BM, WG_CLB, WG_PIXC><<<grid, 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb);
+    slab_reduce_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len);
+    return pgan_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W[Cs,Cl,4,4], stride 2, pad 1).  H = hs.
+int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
+    if (N <= 0) return PGAN_OK;
+    if (Cl == 1) {
+        if (hs != 32 || Cs > 64) return PGAN_EINVAL;
+        conv_down_c1_kernel<32><<<N * (32 / 8), 256, 0, st>>>(L, W, S, N, Cs);
+        return pgan_launch_status();
+    }
+    switch (hs) {
+        case 4: return launch_down<4>(L, W, S, N, Cs, Cl, st);
+        case 8: return launch_down<8>(L, W, S, N, Cs, Cl, st);
+        case 16: return launch_down<16>(L, W, S, N, Cs, Cl, st);
+        default: return PGAN_EINVAL;
+    }
+}
+
+// L[N,Cl,2H,2H] = conv_transpose2d(S[N,Cs,H,H], W[Cs,Cl,4,4], stride 2, pad 1); act: 0 none, 1 sigmoid,
+// 2 tanh (only for Cl == 1).
+int pgan_conv_up(const float* S, const float* W, float* L, int N, int Cs, int Cl, int hs, int act, hipStream_t st) {
+    if (N <= 0) return PGAN_OK;
+    if (Cl == 1) {
+        if (hs != 32 || Cs > 64 || Cs % 16) return PGAN_EINVAL;
+        conv_up_c1_kernel<32><<<N * (32 / 8), 256, 0, st>>>(S, W, L, N, Cs, act);
+        return pgan_launch_status();
+    }
+    if (act != 0) return PGAN_EINVAL;
+    switch (hs) {
+        case 4: return launch_up<4>(S, W, L, N, Cs, Cl, st);
+        case 8: return launch_up<8>(S, W, L, N, Cs, Cl, st);
+        case 16: return launch_up<16>(S, W, L, N, Cs, Cl, st);
+        default: return PGAN_EINVAL;
+    }
+}
+
+// Scratch floats pgan_conv_wgrad needs for these dimensions.
+long long pgan_conv_wgrad_workspace_floats(int N, int Cs, int Cl, int hs) {
+    if (Cl == 1) return (long long)N * Cs * 16;
+    int ns = 1;
+    switch (hs) {
+        case 4: ns = wgrad_splits<4>(N, Cs, Cl); break;
+        case 8: ns = wgrad_splits<8>(N, Cs, Cl); break;
+        case 16: ns = wgrad_splits<16>(N, Cs, Cl); break;
+        default: return -1;
+    }
+    return (long long)ns * Cs * Cl * 16;
+}
+
+// dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)],  r(n) = n (n < n_keep), n + n_swap (n < n_keep + n_swap), else n - n_swap.
+int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+                    int hs, int n_keep, int n_swap, hipStream_t st) {
+    if (N <= 0) return PGAN_EINVAL;
+    if (Cl == 1) {
+        if (hs != 32 || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
+        conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
+        rows_sum_kernel<<<(Cs * 16 + 255) / 256, 256, 0, st>>>(ws, Cs * 16, dW, Cs * 16, 0, N, 0, 0, 0);
+        return pgan_launch_status();
+    }
+    switch (hs) {
+        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        default: return PGAN_EINVAL;
+    }
+}
+
+// out[c] (+)= sum of part[r * ld + c] over rows [r0, r1) and [r2, r3), c < C.
+int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r1, int r2, int r3, int accumulate,
+                     hipStream_t st) {
+    if (C <= 0 || ld < C) return PGAN_EINVAL;
+    rows_sum_kernel<<<(C + 255) / 256, 256, 0, st>>>(part, ld, out, C, r0, r1, r2, r3, accumulate);
+    return pgan_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+// GroupNorm(1,C)+LeakyReLU (discriminator, per-sample statistics) and training-mode
+// BatchNorm+LeakyReLU (generator, per-channel batch statistics): forward, backward, and for
+// GroupNorm the tangent (JVP) and second-order backward the analytic penalty gradients need.
+// HBM/L2-bound streaming kernels: float4 accesses, fp32 per-thread partial sums, fp64
+// cross-thread reductions.  Reference ops: src/layers.py:442-465 (GroupNorm), :93-108,:119-134
+// (BatchNorm), LeakyReLU(0.1) throughout.
+//
+// Notation per sample (M = C*HW elements): xh = (a - mu) * r, r = rsqrt(var + eps),
+// y = gamma_c xh + beta_c, h = lrelu(y), m = lrelu'(y).  J = r (I - 11^T/M - xh xh^T/M) is both
+// the Jacobian d xh / d a and (being symmetric) its transpose.
+#include "pgan_common.h"
+
+namespace {
+
+constexpr int NT = 1024;  // threads per block for the per-sample kernels
+
+// Adds v into sh[c] after reducing it over the GL consecutive lanes that share channel c.
+template <int NV>
+__device__ __forceinline__ void channel_accumulate(float (&v)[NV], float* const (&sh)[NV], int c, int GL) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float x = v[i];
+        for (int o = 1; o < GL; o <<= 1) x += __shfl_xor(x, o, 64);
+        if ((lane & (GL - 1)) == 0) atomicAdd(&sh[i][c], x);
+    }
+}
+
+__global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ h,
+                                                    float* __restrict__ stats, int M, int HW) {
+    __shared__ double sh[2 * NT / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + (int64_t)n * M);
+    f32x4* h4 = reinterpret_cast<f32x4*>(h + (int64_t)n * M);
+    float s = 0.f, ss = 0.f;
+    for (int i = tid; i < M / 4; i += NT) {
+        const f32x4 v = a4[i];
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    double red[2] = {s, ss};
+    block_sum<2>(red, sh);
+    const double mu_d = red[0] / M;
+    const double var = fmax(red[1] / M - mu_d * mu_d, 0.0);
+    const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
+    if (tid == 0) {
+        stats[2 * n] = mu;
+        stats[2 * n + 1] = r;
+    }
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c], b = beta[c];
+        const f32x4 v = a4[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + b);
+        h4[i] = o;
+    }
+}
+
+// first-order backward: d = J (gamma m u); per-sample stats (mean w, mean w xh); per-sample
+// per-channel partial sums of the gamma / beta gradients.
+__global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u, const float* __restrict__ h,
+                                                    const float* __restrict__ a, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, float* __restrict__ d,
+                                                    float* __restrict__ stats_b, float* __restrict__ pg,
+                                                    float* __restrict__ pb, int M, int HW, int C) {
+    __shared__ double sh[2 * NT / 64];
+    __shared__ float cg[512], cb[512];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int GL = min(64, HW / 4);
+    const int64_t base = (int64_t)n * M;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
+    f32x4* d4 = reinterpret_cast<f32x4*>(d + base);
+    const float mu = stats[2 * n], r = stats[2 * n + 1];
+    for (int c = tid; c < C; c += NT) { cg[c] = 0.f; cb[c] = 0.f; }
+    __syncthreads();
+    float sw = 0.f, swx = 0.f;
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c];
+        const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
+        float pe[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - mu) * r, ee = lrelu_mask(hv[e]) * uv[e], w = g * ee;
+            sw += w;
+            swx += w * xh;
+            pe[0] += ee * xh;
+            pe[1] += ee;
+        }
+        float* const dst[2] = {cg, cb};
+        channel_accumulate<2>(pe, dst, c, GL);
+    }
+    double red[2] = {sw, swx};
+    block_sum<2>(red, sh);   // also orders the LDS atomics before the reads below
+    const float mw = (float)(red[0] / M), mwx = (float)(red[1] / M);
+    if (tid == 0) {
+        stats_b[2 * n] = mw;
+        stats_b[2 * n + 1] = mwx;
+    }
+    for (int c = tid; c < C; c += NT) {
+        pg[(int64_t)n * C + c] = cg[c];
+        pb[(int64_t)n * C + c] = cb[c];
+    }
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c];
+        const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - mu) * r, w = g * lrelu_mask(hv[e]) * uv[e];
+            o[e] = r * (w - mw - xh * mwx);
+        }
+        d4[i] = o;
+    }
+}
+
+// tangent forward: hd = m gamma J t.  Primal state (h, a, stats) of sample n; stats_t = (mean t, mean xh t).
+__global__ __launch_bounds__(NT) void gn_jvp_kernel(const float* __restrict__ t, const float* __restrict__ h,
+                                                    const float* __restrict__ a, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, float* __restrict__ hd,
+                                                    float* __restrict__ stats_t, int M, int HW) {
+    __shared__ double sh[2 * NT / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int64_t base = (int64_t)n * M;
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
+    f32x4* o4 = reinterpret_cast<f32x4*>(hd + base);
+    const float mu = stats[2 * n], r = stats[2 * n + 1];
+    float st = 0.f, sxt = 0.f;
+    for (int i = tid; i < M / 4; i += NT) {
+        const f32x4 tv = t4[i], av = a4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            st += tv[e];
+            sxt += (av[e] - mu) * r * tv[e];
+        }
+    }
+    double red[2] = {st, sxt};
+    block_sum<2>(red, sh);
+    const float tb = (float)(red[0] / M), c_ = (float)(red[1] / M);
+    if (tid == 0) {
+        stats_t[2 * n] = tb;
+        stats_t[2 * n + 1] = c_;
+    }
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c];
+        const f32x4 tv = t4[i], hv = h4[i], av = a4[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - mu) * r;
+            o[e] = lrelu_mask(hv[e]) * g * (r * (tv[e] - tb - xh * c_));
+        }
+        o4[i] = o;
+    }
+}
+
+// second-order backward of S = <hbar-path> + sum tangent score, for the primal input a:
+//   w = gamma m u, q = gamma m hbar, Q = q - r (c w + mwx t)
+//   p = r [ Q - mean Q - xh (mean(Q xh) + mean(w xd)) ],  xd = r (t - tb - xh c)
+// plus per-channel partials  pg = sum m u xd + m hbar xh,  pb = sum m hbar.   hbar may be null (= 0).
+__global__ __launch_bounds__(NT) void gn_bwd2_kernel(const float* __restrict__ hbar, const float* __restrict__ u,
+                                                     const float* __restrict__ t, const float* __restrict__ h,
+                                                     const float* __restrict__ a, const float* __restrict__ stats,
+                                                     const float* __restrict__ stats_b, const float* __restrict__ stats_t,
+                                                     const float* __restrict__ gamma, float* __restrict__ p,
+                                                     float* __restrict__ pg, float* __restrict__ pb, int M, int HW, int C) {
+    __shared__ double sh[3 * NT / 64];
+    __shared__ float cg[512], cb[512];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int GL = min(64, HW / 4);
+    const int64_t base = (int64_t)n * M;
+    const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + base) : nullptr;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + base);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
+    f32x4* p4 = reinterpret_cast<f32x4*>(p + base);
+    const float mu = stats[2 * n], r = stats[2 * n + 1];
+    const float mw = stats_b[2 * n], mwx = stats_b[2 * n + 1];
+    const float tb = stats_t[2 * n], c_ = stats_t[2 * n + 1];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int c = tid; c < C; c += NT) { cg[c] = 0.f; cb[c] = 0.f; }
+    __syncthreads();
+    float sq = 0.f, sqx = 0.f, swt = 0.f;
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c];
+        const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        float pe[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - mu) * r, m = lrelu_mask(hv[e]);
+            const float q = g * m * bv[e], w = g * m * uv[e];
+            const float xd = r * (tv[e] - tb - xh * c_);
+            sq += q;
+            sqx += q * xh;
+            swt += w * tv[e];
+            pe[0] += m * uv[e] * xd + m * bv[e] * xh;
+            pe[1] += m * bv[e];
+        }
+        float* const dst[2] = {cg, cb};
+        channel_accumulate<2>(pe, dst, c, GL);
+    }
+    double red[3] = {sq, sqx, swt};
+    block_sum<3>(red, sh);
+    const float mq = (float)(red[0] / M), mqx = (float)(red[1] / M), mwt = (float)(red[2] / M);
+    const float mQ = mq - r * (c_ * mw + mwx * tb);
+    const float mQx = mqx - 2.f * r * c_ * mwx;
+    const float mwxd = r * (mwt - mw * tb - mwx * c_);
+    const float kx = mQx + mwxd;
+    for (int c = tid; c < C; c += NT) {
+        pg[(int64_t)n * C + c] = cg[c];
+        pb[(int64_t)n * C + c] = cb[c];
+    }
+    for (int i = tid; i < M / 4; i += NT) {
+        const int c = (i * 4) / HW;
+        const float g = gamma[c];
+        const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[e] - mu) * r, m = lrelu_mask(hv[e]);
+            const float q = g * m * bv[e], w = g * m * uv[e];
+            const float Q = q - r * (c_ * w + mwx * tv[e]);
+            o[e] = r * (Q - mQ - xh * kx);
+        }
+        p4[i] = o;
+    }
+}
+
+// ---------------- BatchNorm (training mode) + LeakyReLU: one block per channel ----------------
+constexpr int BT = 256;
+
+__global__ __launch_bounds__(BT) void bn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ rmean,
+                                                    float* __restrict__ rvar, float* __restrict__ h,
+                                                    float* __restrict__ stats, int B, int C, int HW, float momentum) {
+    __shared__ double sh[2 * BT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int q = HW / 4, total = B * q;   // float4 units
+    float s = 0.f, ss = 0.f;
+    for (int i = tid; i < total; i += BT) {
+        const int b = i / q, p = i % q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + ((int64_t)b * C + c) * HW + p * 4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    double red[2] = {s, ss};
+    block_sum<2>(red, sh);
+    const double cnt = (double)B * HW;
+    const double mu_d = red[0] / cnt;
+    const double var = fmax(red[1] / cnt - mu_d * mu_d, 0.0);
+    const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
+    if (tid == 0) {
+        stats[c] = mu;
+        stats[C + c] = r;
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma[c], bt = beta[c];
+    for (int i = tid; i < total; i += BT) {
+        const int b = i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
+        *reinterpret_cast<f32x4*>(h + off) = o;
+    }
+}
+
+__global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                    const float* __restrict__ a, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, float* __restrict__ da,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
+                                                    int HW) {
+    __shared__ double sh[2 * BT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int q = HW / 4, total = B * q;
+    const float mu = stats[c], r = stats[C + c], g = gamma[c];
+    float sb = 0.f, sg = 0.f;
+    for (int i = tid; i < total; i += BT) {
+        const int b = i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + off);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + off);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dy = lrelu_mask(hv[e]) * dv[e];
+            sb += dy;
+            sg += dy * ((av[e] - mu) * r);
+        }
+    }
+    double red[2] = {sb, sg};
+    block_sum<2>(red, sh);
+    const double cnt = (double)B * HW;
+    const float mb = (float)(red[0] / cnt), mg = (float)(red[1] / cnt);
+    if (tid == 0) {
+        dbeta[c] = (float)red[0];
+        dgamma[c] = (float)red[1];
+    }
+    for (int i = tid; i < total; i += BT) {
+        const int b = i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + off);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + off);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dy = lrelu_mask(hv[e]) * dv[e], xh = (av[e] - mu) * r;
+            o[e] = g * r * (dy - mb - xh * mg);
+        }
+        *reinterpret_cast<f32x4*>(da + off) = o;
+    }
+}
+
+bool gn_shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && C <= 512 && HW >= 16 && (HW & (HW - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// h = lrelu(GroupNorm(1,C)(a)); stats[n] = (mean, rstd).  a, h: [N, C, HW].
+int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C, int HW,
+                hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
+    gn_fwd_kernel<<<N, NT, 0, st>>>(a, gamma, beta, h, stats, C * HW, HW);
+    return pgan_launch_status();
+}
+
+int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
+                float* stats_b, float* pg, float* pb, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
+    gn_bwd_kernel<<<N, NT, 0, st>>>(u, h, a, stats, gamma, d, stats_b, pg, pb, C * HW, HW, C);
+    return pgan_launch_status();
+}
+
+int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
+                float* stats_t, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
+    gn_jvp_kernel<<<N, NT, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, C * HW, HW);
+    return pgan_launch_status();
+}
+
+int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
+                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int N,
+                 int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
+    gn_bwd2_kernel<<<N, NT, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, C * HW, HW, C);
+    return pgan_launch_status();
+}
+
+// a, h: [B, C, HW] (HW multiple of 4); stats: [2, C] = (batch mean, rstd); running stats updated in place.
+int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h, float* stats,
+                int B, int C, int HW, float momentum, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
+    bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum);
+    return pgan_launch_status();
+}
+
+int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
+                float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
+    bn_bwd_kernel<<<C, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, B, C, HW);
+    return pgan_launch_status();
+}
+
+}  // extern "C"

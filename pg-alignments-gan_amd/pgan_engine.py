@@ -254,7 +254,7 @@ class Engine:
                 o.conv_up(self.gH[i], w, self.gA[i + 1])
             else:
                 o.conv_up(self.gH[i], w, out_s, self.act_id)
-        o.convt1d_s1(self.Z, G["oned_conv_layers.0.weight"], self.hA[1])
+        o.gemm_nn(self.Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), self.hA[1].view(self.B, -1))
         for i in range(1, 5):
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
             o.bn_fwd(self.hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"], Gb[n + ".running_var"],

@@ -1,0 +1,313 @@
+"""ctypes binding of libpgan_hip.so (the C-ABI declared in include/pgan_hip.h) and HipOps, the op
+backend the engine drives.  There is no fallback: if the library is missing, import fails; if an
+entry point rejects its arguments or HIP reports a launch error, PganError is raised.
+
+Tensors are torch CUDA tensors used as plain device buffers (data_ptr + shape); every call only
+enqueues kernels on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_void_p
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgan_hip.so")
+
+
+class PganError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    return ctypes.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+P, I, L, F = c_void_p, c_int, c_longlong, c_float
+_SIGS = {
+    "pgan_conv_down": [P, P, P, I, I, I, I, P],
+    "pgan_conv_up": [P, P, P, I, I, I, I, I, P],
+    "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, P],
+    "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
+    "pgan_gn_fwd": [P, P, P, P, P, I, I, I, P],
+    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_gn_jvp": [P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_bn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
+    "pgan_bn_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
+    "pgan_head_seed": [P, P, P, I, I, P],
+    "pgan_head_wgrad": [P, P, P, I, I, P],
+    "pgan_interpolate": [P, P, P, P, I, I, P],
+    "pgan_gp_penalty": [P, P, P, P, L, F, P],
+    "pgan_div_penalty": [P, P, P, P, I, I, P],
+    "pgan_critic_loss": [P, P, P, I, P],
+    "pgan_sum_scale": [P, P, I, F, P],
+    "pgan_act_bwd": [P, P, P, L, I, P],
+    "pgan_affine": [P, P, L, F, F, P],
+    "pgan_adam": [P, P, P, P, L, F, F, F, F, P, I, P],
+    "pgan_philox": [P, L, P, I, P],
+    "pgan_d1d_fwd": [P, P, P, P, P, P, I, P],
+    "pgan_d1d_bwd": [P, P, P, P, P, P, P, P, I, P, P, I, P],
+    "pgan_ct1d_up": [P, P, P, I, I, I, I, I, P],
+    "pgan_ct1d_down": [P, P, P, I, I, I, I, P],
+    "pgan_ct1d_wgrad": [P, P, P, I, I, I, I, P],
+    "pgan_gemm": [P, P, P, I, I, I, I, P],
+}
+EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats"])
+for _name, _args in _SIGS.items():
+    _fn = getattr(_lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = c_int
+_lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
+_lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise PganError(f"expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise PganError(f"{what} failed with code {rc} ({'bad shape/argument' if rc == -1 else 'HIP launch error'})")
+
+
+def _hw(t: torch.Tensor) -> int:
+    n = 1
+    for d in t.shape[2:]:
+        n *= d
+    return n
+
+
+D1_PACKED = (64, 16, 16, 16, 2048, 32, 32, 32, 8192, 64, 64, 64)   # cw cb gw gb per 1-D stage
+
+
+class HipOps:
+    """Same method signatures as tests/torch_ops.TorchOps; every method writes into caller tensors."""
+    name = "hip"
+
+    def __init__(self, device=None, ws_floats: int = 16 * 1024 * 1024, max_samples: int = 1024):
+        if not torch.cuda.is_available():
+            raise PganError("HipOps needs a GPU")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ws = torch.empty(ws_floats, dtype=torch.float32, device=self.device)
+        self.ws_small = torch.empty(4096, dtype=torch.float32, device=self.device)
+        self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
+        self.max_samples = max_samples
+        self._keep = []   # host-side arrays that must outlive an enqueue call
+
+    # ---------------- conv family ----------------
+    def conv_down(self, x, w, y):
+        N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
+        Cs, hs = w.shape[0], HL // 2
+        assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
+        _check(_lib.pgan_conv_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down")
+
+    def conv_up(self, y, w, x, act=0):
+        N, Cs, hs = y.shape[0], y.shape[1], y.shape[2]
+        Cl = w.shape[1]
+        assert tuple(x.shape) == (N, Cl, 2 * hs, 2 * hs) and w.shape[0] == Cs
+        _check(_lib.pgan_conv_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, hs, act, _stream()), "pgan_conv_up")
+
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0):
+        N, Cs, hs = ya.shape[0], ya.shape[1], ya.shape[2]
+        Cl = x.shape[1]
+        if n_keep is None:
+            n_keep = N
+        assert tuple(dw.shape[:2]) == (Cs, Cl) and x.shape[0] >= N and x.shape[2] == 2 * hs
+        need = _lib.pgan_conv_wgrad_workspace_floats(N, Cs, Cl, hs)
+        if need < 0 or need > self.ws.numel():
+            raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
+        _check(_lib.pgan_conv_wgrad(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs,
+                                    n_keep, n_swap, _stream()), "pgan_conv_wgrad")
+
+    def rows_reduce(self, part, out, r0, r1, r2, r3, accumulate=False):
+        C = part.shape[1]
+        assert out.numel() == C
+        _check(_lib.pgan_rows_reduce(_ptr(part), C, _ptr(out), C, r0, r1, r2, r3, int(accumulate), _stream()),
+               "pgan_rows_reduce")
+
+    # ---------------- GroupNorm family ----------------
+    def gn_fwd(self, a, gamma, beta, h, stats):
+        N, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), N, C, _hw(a), _stream()),
+               "pgan_gn_fwd")
+
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
+        N, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b), _ptr(pg),
+                                _ptr(pb), N, C, _hw(a), _stream()), "pgan_gn_bwd")
+
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
+        N, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(hd), _ptr(stats_t), N, C,
+                                _hw(a), _stream()), "pgan_gn_jvp")
+
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
+        N, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
+                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _ptr(pg), _ptr(pb), N, C, _hw(a), _stream()),
+               "pgan_gn_bwd2")
+
+    # ---------------- BatchNorm ----------------
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
+        B, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats), B, C,
+                                _hw(a), momentum, _stream()), "pgan_bn_fwd")
+
+    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
+        B, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_bn_bwd(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
+                                _ptr(dbeta), B, C, _hw(a), _stream()), "pgan_bn_bwd")
+
+    # ---------------- head ----------------
+    def head_fwd(self, h4, f1, w, b, score):
+        N = h4.shape[0]
+        K2, K1 = h4[0].numel(), f1[0].numel()
+        assert w.numel() == K2 + K1 and score.numel() == N
+        _check(_lib.pgan_head_fwd(_ptr(h4), _ptr(f1), _ptr(w), _ptr(b), _ptr(score), N, K2, K1, _stream()),
+               "pgan_head_fwd")
+
+    def head_seed(self, w, coef, u4):
+        N, K = u4.shape[0], u4[0].numel()
+        assert coef.numel() == N
+        _check(_lib.pgan_head_seed(_ptr(w), _ptr(coef), _ptr(u4), N, K, _stream()), "pgan_head_seed")
+
+    def head_wgrad(self, x, coef, dw):
+        N, J = x.shape[0], x[0].numel()
+        assert coef.numel() == N and dw.numel() == J
+        _check(_lib.pgan_head_wgrad(_ptr(x), _ptr(coef), _ptr(dw), N, J, _stream()), "pgan_head_wgrad")
+
+    # ---------------- penalties / losses ----------------
+    def interpolate(self, t, real, fake, out):
+        B, M = real.shape[0], real[0].numel()
+        _check(_lib.pgan_interpolate(_ptr(t), _ptr(real), _ptr(fake), _ptr(out), B, M, _stream()), "pgan_interpolate")
+
+    def gp_penalty(self, g, lam, v, pen):
+        _check(_lib.pgan_gp_penalty(_ptr(g), _ptr(v), _ptr(pen), _ptr(self.ws_small), g.numel(), float(lam), _stream()),
+               "pgan_gp_penalty")
+
+    def div_penalty(self, g, nb, v, pen):
+        assert g.shape[0] == 2 * nb and 2 * nb <= self.ws_small.numel()
+        _check(_lib.pgan_div_penalty(_ptr(g), _ptr(v), _ptr(pen), _ptr(self.ws_small), nb, g[0].numel(), _stream()),
+               "pgan_div_penalty")
+
+    def critic_loss(self, score, nb, pen, out):
+        _check(_lib.pgan_critic_loss(_ptr(score), _ptr(pen), _ptr(out), nb, _stream()), "pgan_critic_loss")
+
+    def neg_mean(self, score, out):
+        n = score.numel()
+        _check(_lib.pgan_sum_scale(_ptr(score), _ptr(out), n, -1.0 / n, _stream()), "pgan_sum_scale")
+
+    def act_bwd(self, dy, y, dx, act):
+        _check(_lib.pgan_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), act, _stream()), "pgan_act_bwd")
+
+    def affine(self, x, scale, shift, out):
+        _check(_lib.pgan_affine(_ptr(x), _ptr(out), x.numel(), float(scale), float(shift), _stream()), "pgan_affine")
+
+    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None):
+        sd = None if step_dev is None else step_dev.data_ptr()
+        _check(_lib.pgan_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, b1, b2, eps, sd, int(step), _stream()),
+               "pgan_adam")
+
+    def philox(self, out, state, normal: bool):
+        _check(_lib.pgan_philox(_ptr(out), out.numel(), state.data_ptr(), int(normal), _stream()), "pgan_philox")
+
+    # ---------------- discriminator 1-D tower ----------------
+    @staticmethod
+    def _param_array(cw, cb, gw, gb):
+        arr = (c_void_p * 12)()
+        for i in range(3):
+            arr[4 * i + 0] = _ptr(cw[i])
+            arr[4 * i + 1] = _ptr(cb[i])
+            arr[4 * i + 2] = _ptr(gw[i])
+            arr[4 * i + 3] = _ptr(gb[i])
+        return arr
+
+    def d1d_fwd(self, xp, cw, cb, gw, gb, a_save, feat):
+        N = xp.shape[0]
+        arr = self._param_array(cw, cb, gw, gb)
+        _check(_lib.pgan_d1d_fwd(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(feat), N,
+                                 _stream()), "pgan_d1d_fwd")
+
+    def d1d_bwd(self, xp, cw, cb, gw, gb, a_save, coef, w_tail, d_cw, d_cb, d_gw, d_gb, dxp):
+        N = xp.shape[0]
+        arr = self._param_array(cw, cb, gw, gb)
+        part, ld, offs, dsts = None, 0, None, None
+        if d_cw is not None:
+            if N > self.max_samples:
+                raise PganError(f"d1d_bwd: {N} samples exceed the partial-gradient scratch ({self.max_samples})")
+            dsts = []
+            for i in range(3):
+                dsts += [d_cw[i], d_cb[i], d_gw[i], d_gb[i]]
+            base = min(t.data_ptr() for t in dsts)
+            rel = [(t.data_ptr() - base) // 4 for t in dsts]
+            span = max(r + t.numel() for r, t in zip(rel, dsts))
+            flat = span <= sum((t.numel() + 63) // 64 * 64 for t in dsts) and all(_ptr(t) is not None for t in dsts)
+            if not flat:   # destinations are unrelated tensors: packed rows, one reduction per tensor
+                rel, acc = [], 0
+                for s in D1_PACKED:
+                    rel.append(acc)
+                    acc += s
+                span = acc
+            ld = span
+            offs = (c_int * 12)(*rel)
+            part = self.d1_part
+        _check(_lib.pgan_d1d_bwd(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(coef),
+                                 _ptr(w_tail), _ptr(part), ld, offs, _ptr(dxp), N, _stream()), "pgan_d1d_bwd")
+        if d_cw is not None:
+            if flat:
+                first = min(dsts, key=lambda t: t.data_ptr())
+                _check(_lib.pgan_rows_reduce(_ptr(part), ld, first.data_ptr(), ld, 0, N, 0, 0, 0, _stream()),
+                       "pgan_rows_reduce")
+            else:
+                for r, t in zip(rel, dsts):
+                    _check(_lib.pgan_rows_reduce(part.data_ptr() + 4 * r, ld, _ptr(t), t.numel(), 0, N, 0, 0, 0,
+                                                 _stream()), "pgan_rows_reduce")
+
+    # ---------------- generator pieces ----------------
+    def gemm_nn(self, a, b, c):
+        M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K and tuple(c.shape) == (M, N)
+        _check(_lib.pgan_gemm(_ptr(a), _ptr(b), _ptr(c), M, N, K, 0, _stream()), "pgan_gemm")
+
+    def gemm_tn(self, a, b, c):
+        K, M = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K and tuple(c.shape) == (M, N)
+        _check(_lib.pgan_gemm(_ptr(a), _ptr(b), _ptr(c), M, N, K, 1, _stream()), "pgan_gemm")
+
+    def convt1d_up(self, y, w, x, act=0):
+        N, Cs, Ls = y.shape
+        Cl = w.shape[1]
+        assert tuple(x.shape) == (N, Cl, 2 * Ls)
+        _check(_lib.pgan_ct1d_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, Ls, act, _stream()), "pgan_ct1d_up")
+
+    def convt1d_down(self, x, w, y):
+        N, Cs, Ls = y.shape
+        Cl = w.shape[1]
+        assert tuple(x.shape) == (N, Cl, 2 * Ls)
+        _check(_lib.pgan_ct1d_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, Ls, _stream()), "pgan_ct1d_down")
+
+    def convt1d_wgrad(self, ya, x, dw):
+        N, Cs, Ls = ya.shape
+        Cl = x.shape[1]
+        assert tuple(dw.shape) == (Cs, Cl, 4)
+        _check(_lib.pgan_ct1d_wgrad(_ptr(ya), _ptr(x), _ptr(dw), N, Cs, Cl, Ls, _stream()), "pgan_ct1d_wgrad")

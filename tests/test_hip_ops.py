@@ -1,0 +1,343 @@
+"""Per-kernel parity on the GPU: every HIP op (through the C-ABI) against the plain-torch statement
+of the same op (tests/torch_ops.py) evaluated in float64 on the CPU, same inputs.
+
+Tolerance: 1e-5 norm-wise relative error in fp32 (the north star's bound), with the elementwise
+error measured against the tensor's rms allowed 5e-5 for long reductions."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_rel_err, rel_err
+from torch_ops import TorchOps
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pgan_hip import HipOps
+    return HipOps(torch.device("cuda:0"))
+
+
+REF = TorchOps()
+DEV = "cuda:0"
+
+
+def rnd(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def d64(*ts):
+    return [None if t is None else ([d64(x)[0] for x in t] if isinstance(t, (list, tuple)) else t.double()) for t in ts]
+
+
+def gpu(*ts):
+    return [None if t is None else ([x.to(DEV) for x in t] if isinstance(t, (list, tuple)) else t.to(DEV)) for t in ts]
+
+
+def close(name, got, want, rtol=RTOL, etol=5e-5):
+    r, m = rel_err(got, want), max_rel_err(got, want)
+    print(f"{name}: rel {r:.2e} max/rms {m:.2e}")
+    assert r < rtol, f"{name}: norm-wise rel err {r:.3e}"
+    assert m < etol, f"{name}: max err / rms {m:.3e}"
+
+
+LAYERS = [(128, 64, 16), (256, 128, 8), (512, 256, 4)]   # (Cs, Cl, hs)
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
+@pytest.mark.parametrize("N", [5, 8])
+def test_conv_down(hip, Cs, Cl, hs, N):
+    rng = np.random.default_rng(1)
+    x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+    REF.conv_down(*d64(x, w), want)
+    got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+    hip.conv_down(*gpu(x, w), got)
+    close("conv_down", got, want)
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
+@pytest.mark.parametrize("N", [5, 8])
+def test_conv_up(hip, Cs, Cl, hs, N):
+    rng = np.random.default_rng(2)
+    y, w = rnd(rng, N, Cs, hs, hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    want = torch.zeros(N, Cl, 2 * hs, 2 * hs, dtype=torch.float64)
+    REF.conv_up(*d64(y, w), want)
+    got = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
+    hip.conv_up(*gpu(y, w), got)
+    close("conv_up", got, want)
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
+@pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (12, 0, 6)])
+def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap):
+    rng = np.random.default_rng(3)
+    ya, x = rnd(rng, N, Cs, hs, hs), rnd(rng, N, Cl, 2 * hs, 2 * hs)
+    want = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
+    REF.conv_wgrad(*d64(ya, x), want, keep, swap)
+    got = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
+    hip.conv_wgrad(*gpu(ya, x), got, keep, swap)
+    close("conv_wgrad", got, want)
+
+
+@pytest.mark.parametrize("N", [1, 3])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv_c1(hip, N, act):
+    rng = np.random.default_rng(4)
+    Cs, hs = 64, 32
+    x, w, y = rnd(rng, N, 1, 64, 64), rnd(rng, Cs, 1, 4, 4, scale=0.2), rnd(rng, N, Cs, hs, hs)
+    want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+    REF.conv_down(*d64(x, w), want)
+    got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+    hip.conv_down(*gpu(x, w), got)
+    close("conv_down_c1", got, want)
+    want = torch.zeros(N, 1, 64, 64, dtype=torch.float64)
+    REF.conv_up(*d64(y, w * 0.2), want, act)
+    got = torch.full((N, 1, 64, 64), float("nan"), device=DEV)
+    hip.conv_up(*gpu(y, w * 0.2), got, act)
+    close("conv_up_c1", got, want)
+    want = torch.zeros(Cs, 1, 4, 4, dtype=torch.float64)
+    REF.conv_wgrad(*d64(y, x), want, 1, 1 if N == 3 else 0)
+    got = torch.full((Cs, 1, 4, 4), float("nan"), device=DEV)
+    hip.conv_wgrad(*gpu(y, x), got, 1, 1 if N == 3 else 0)
+    close("conv_wgrad_c1", got, want)
+
+
+GN_SHAPES = [(64, 32), (128, 16), (256, 8), (512, 4)]
+
+
+@pytest.mark.parametrize("C,hs", GN_SHAPES)
+def test_groupnorm_family(hip, C, hs):
+    rng = np.random.default_rng(5)
+    N = 3
+    sh = (N, C, hs, hs)
+    a = rnd(rng, *sh) * 0.7 + 0.3
+    gamma, beta = 1 + 0.2 * rnd(rng, C), 0.2 * rnd(rng, C)
+    u, t, hbar = rnd(rng, *sh), rnd(rng, *sh), rnd(rng, *sh)
+    # forward
+    h_w, st_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
+    REF.gn_fwd(*d64(a, gamma, beta), h_w, st_w)
+    h_g, st_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
+    hip.gn_fwd(*gpu(a, gamma, beta), h_g, st_g)
+    close("gn_fwd.h", h_g, h_w)
+    close("gn_fwd.stats", st_g, st_w)
+    h32 = h_g.cpu()   # masks come from the GPU's own forward output
+    # first-order backward
+    d_w, sb_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
+    pg_w, pb_w = torch.zeros(N, C, dtype=torch.float64), torch.zeros(N, C, dtype=torch.float64)
+    REF.gn_bwd(*d64(u, h32, a), st_w, gamma.double(), d_w, sb_w, pg_w, pb_w)
+    d_g, sb_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
+    pg_g, pb_g = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV)
+    hip.gn_bwd(*gpu(u), h_g, a.to(DEV), st_g, gamma.to(DEV), d_g, sb_g, pg_g, pb_g)
+    close("gn_bwd.d", d_g, d_w)
+    close("gn_bwd.pg", pg_g, pg_w)
+    close("gn_bwd.pb", pb_g, pb_w)
+    # tangent
+    hd_w, stt_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
+    REF.gn_jvp(*d64(t, h32, a), st_w, gamma.double(), hd_w, stt_w)
+    hd_g, stt_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
+    hip.gn_jvp(t.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), hd_g, stt_g)
+    close("gn_jvp.hd", hd_g, hd_w)
+    # second-order backward, with and without an incoming primal adjoint
+    for hb in (hbar, None):
+        p_w = torch.zeros(sh, dtype=torch.float64)
+        REF.gn_bwd2(None if hb is None else hb.double(), *d64(u, t, h32, a), st_w, sb_w, stt_w, gamma.double(), p_w,
+                    pg_w, pb_w)
+        p_g = torch.zeros(sh, device=DEV)
+        hip.gn_bwd2(None if hb is None else hb.to(DEV), u.to(DEV), t.to(DEV), h_g, a.to(DEV), st_g, sb_g, stt_g,
+                    gamma.to(DEV), p_g, pg_g, pb_g)
+        close("gn_bwd2.p", p_g, p_w, rtol=2e-5)
+        close("gn_bwd2.pg", pg_g, pg_w, rtol=2e-5)
+        if hb is not None:
+            close("gn_bwd2.pb", pb_g, pb_w)
+        else:
+            assert float(pb_g.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(6, 512, 4, 4), (6, 64, 32, 32), (6, 64, 4), (6, 8, 32)])
+def test_batchnorm(hip, shape):
+    rng = np.random.default_rng(6)
+    C = shape[1]
+    a, dh = rnd(rng, *shape) * 0.5 + 0.2, rnd(rng, *shape)
+    gamma, beta = 1 + 0.2 * rnd(rng, C), 0.2 * rnd(rng, C)
+    rm, rv = 0.1 * rnd(rng, C), 1 + 0.1 * rnd(rng, C).abs()
+    h_w, st_w = torch.zeros(shape, dtype=torch.float64), torch.zeros(2, C, dtype=torch.float64)
+    rm_w, rv_w = rm.double().clone(), rv.double().clone()
+    REF.bn_fwd(*d64(a, gamma, beta), rm_w, rv_w, h_w, st_w)
+    h_g, st_g = torch.zeros(shape, device=DEV), torch.zeros(2, C, device=DEV)
+    rm_g, rv_g = rm.to(DEV), rv.to(DEV)
+    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g)
+    close("bn_fwd.h", h_g, h_w)
+    close("bn_fwd.rmean", rm_g, rm_w)
+    close("bn_fwd.rvar", rv_g, rv_w)
+    da_w = torch.zeros(shape, dtype=torch.float64)
+    dg_w, db_w = torch.zeros(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
+    REF.bn_bwd(*d64(dh, h_g.cpu(), a), st_w, gamma.double(), da_w, dg_w, db_w)
+    da_g, dg_g, db_g = torch.zeros(shape, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    hip.bn_bwd(dh.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), da_g, dg_g, db_g)
+    close("bn_bwd.da", da_g, da_w)
+    close("bn_bwd.dgamma", dg_g, dg_w)
+    close("bn_bwd.dbeta", db_g, db_w)
+
+
+def test_head_and_penalties(hip):
+    rng = np.random.default_rng(7)
+    N, K2, K1 = 6, 8192, 3520
+    h4, f1 = rnd(rng, N, 512, 4, 4), rnd(rng, N, K1)
+    w, b, coef = rnd(rng, 1, K2 + K1, scale=0.01), rnd(rng, 1), rnd(rng, N)
+    want = torch.zeros(N, dtype=torch.float64)
+    REF.head_fwd(*d64(h4, f1, w, b), want)
+    got = torch.zeros(N, device=DEV)
+    hip.head_fwd(*gpu(h4, f1, w, b), got)
+    close("head_fwd", got, want)
+    want = torch.zeros(N, 512, 4, 4, dtype=torch.float64)
+    REF.head_seed(*d64(w, coef), want)
+    got = torch.zeros(N, 512, 4, 4, device=DEV)
+    hip.head_seed(*gpu(w, coef), got)
+    close("head_seed", got, want)
+    want = torch.zeros(K2, dtype=torch.float64)
+    REF.head_wgrad(*d64(h4, coef), want)
+    got = torch.zeros(K2, device=DEV)
+    hip.head_wgrad(*gpu(h4, coef), got)
+    close("head_wgrad", got, want)
+    # interpolate / gp / div
+    B = 4
+    real, fake, t = rnd(rng, B, 1, 64, 64), rnd(rng, B, 1, 64, 64), torch.from_numpy(rng.random(B).astype(np.float32))
+    want = torch.zeros(B, 1, 64, 64, dtype=torch.float64)
+    REF.interpolate(*d64(t, real, fake), want)
+    got = torch.zeros(B, 1, 64, 64, device=DEV)
+    hip.interpolate(*gpu(t, real, fake), got)
+    close("interpolate", got, want)
+    g = rnd(rng, B, 1, 64, 64, scale=0.02)
+    v_w, pen_w = torch.zeros(B, 1, 64, 64, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+    REF.gp_penalty(g.double(), 10.0, v_w, pen_w)
+    v_g, pen_g = torch.zeros(B, 1, 64, 64, device=DEV), torch.zeros(1, device=DEV)
+    hip.gp_penalty(g.to(DEV), 10.0, v_g, pen_g)
+    close("gp.v", v_g, v_w)
+    close("gp.pen", pen_g, pen_w)
+    REF.div_penalty(g.double(), B // 2, v_w, pen_w)
+    hip.div_penalty(g.to(DEV), B // 2, v_g, pen_g)
+    close("div.v", v_g, v_w)
+    close("div.pen", pen_g, pen_w)
+    score, pen = rnd(rng, 2 * B), rnd(rng, 1)
+    out_w = torch.zeros(4, dtype=torch.float64)
+    REF.critic_loss(score.double(), B, pen.double(), out_w)
+    out_g = torch.zeros(4, device=DEV)
+    hip.critic_loss(score.to(DEV), B, pen.to(DEV), out_g)
+    close("critic_loss", out_g, out_w)
+    o_w, o_g = torch.zeros(1, dtype=torch.float64), torch.zeros(1, device=DEV)
+    REF.neg_mean(score.double(), o_w)
+    hip.neg_mean(score.to(DEV), o_g)
+    close("neg_mean", o_g, o_w)
+    y = torch.sigmoid(rnd(rng, B, 1, 64, 64))
+    for act in (1, 2):
+        dx_w, dx_g = torch.zeros(B, 1, 64, 64, dtype=torch.float64), torch.zeros(B, 1, 64, 64, device=DEV)
+        REF.act_bwd(*d64(real, y), dx_w, act)
+        hip.act_bwd(*gpu(real, y), dx_g, act)
+        close("act_bwd", dx_g, dx_w)
+    a_w, a_g = torch.zeros(B, 1, 64, 64, dtype=torch.float64), torch.zeros(B, 1, 64, 64, device=DEV)
+    REF.affine(real.double(), 2.0, -1.0, a_w)
+    hip.affine(real.to(DEV), 2.0, -1.0, a_g)
+    close("affine", a_g, a_w)
+
+
+def test_adam(hip):
+    rng = np.random.default_rng(8)
+    n = 4096 + 64
+    p, g, m = rnd(rng, n, scale=0.05), rnd(rng, n, scale=1e-3), rnd(rng, n, scale=1e-3)
+    v = rnd(rng, n, scale=1e-3).abs() * 1e-3
+    pw, mw, vw = p.double().clone(), m.double().clone(), v.double().clone()
+    pg_, mg, vg = p.to(DEV), m.to(DEV), v.to(DEV)
+    step_dev = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    for step in (7, 8):
+        REF.adam(pw, g.double(), mw, vw, step, 5e-5, 0.5, 0.999, 1e-8)
+    hip.adam(pg_, g.to(DEV), mg, vg, 7, 5e-5, 0.5, 0.999, 1e-8)             # step count from the host
+    hip.adam(pg_, g.to(DEV), mg, vg, 0, 5e-5, 0.5, 0.999, 1e-8, step_dev)   # device counter 7 -> 8
+    close("adam.p", pg_, pw, rtol=1e-6, etol=1e-5)
+    close("adam.m", mg, mw)
+    close("adam.v", vg, vw)
+    assert int(step_dev) == 8
+
+
+def test_philox(hip):
+    state = torch.tensor([1234, 0, 0, 0], dtype=torch.int32, device=DEV)
+    out = torch.zeros(1 << 20, device=DEV)
+    hip.philox(out, state, True)
+    assert abs(float(out.mean())) < 5e-3 and abs(float(out.std()) - 1.0) < 5e-3
+    assert int(state[2]) == (1 << 20) // 4
+    out2 = torch.zeros(1 << 20, device=DEV)
+    hip.philox(out2, state, False)
+    assert 0.0 <= float(out2.min()) and float(out2.max()) < 1.0 and abs(float(out2.mean()) - 0.5) < 2e-3
+    state.copy_(torch.tensor([1234, 0, 0, 0], dtype=torch.int32))
+    out3 = torch.zeros(1 << 20, device=DEV)
+    hip.philox(out3, state, True)
+    assert torch.equal(out, out3)
+
+
+def test_d1d_tower(hip):
+    rng = np.random.default_rng(9)
+    N = 5
+    ch, ln = (1, 16, 32, 64), (64, 61, 58, 55)
+    xp = torch.sort(torch.from_numpy(rng.random((N, 1, 64)).astype(np.float32)), dim=-1).values
+    cw = [rnd(rng, ch[i + 1], ch[i], 4, scale=0.3) for i in range(3)]
+    cb = [rnd(rng, ch[i + 1], scale=0.1) for i in range(3)]
+    gw = [1 + 0.2 * rnd(rng, ch[i + 1]) for i in range(3)]
+    gb = [0.2 * rnd(rng, ch[i + 1]) for i in range(3)]
+    coef, w_tail = rnd(rng, N), rnd(rng, 3520, scale=0.02)
+    a_w = [torch.zeros(N, ch[i + 1], ln[i + 1], dtype=torch.float64) for i in range(3)]
+    f_w = torch.zeros(N, 3520, dtype=torch.float64)
+    REF.d1d_fwd(*d64(xp, cw, cb, gw, gb), a_w, f_w)
+    a_g = [torch.zeros(N, ch[i + 1], ln[i + 1], device=DEV) for i in range(3)]
+    f_g = torch.zeros(N, 3520, device=DEV)
+    hip.d1d_fwd(*gpu(xp, cw, cb, gw, gb), a_g, f_g)
+    close("d1d_fwd.feat", f_g, f_w)
+    for i in range(3):
+        close(f"d1d_fwd.a{i}", a_g[i], a_w[i])
+    zw = lambda ts: [torch.zeros_like(t, dtype=torch.float64) for t in ts]
+    zg = lambda ts: [torch.zeros_like(t, device=DEV) for t in ts]
+    dw_w, db_w, dgw_w, dgb_w = zw(cw), zw(cb), zw(gw), zw(gb)
+    dx_w = torch.zeros(N, 1, 64, dtype=torch.float64)
+    REF.d1d_bwd(*d64(xp, cw, cb, gw, gb), a_w, coef.double(), w_tail.double(), dw_w, db_w, dgw_w, dgb_w, dx_w)
+    dw_g, db_g, dgw_g, dgb_g = zg(cw), zg(cb), zg(gw), zg(gb)
+    dx_g = torch.zeros(N, 1, 64, device=DEV)
+    hip.d1d_bwd(*gpu(xp, cw, cb, gw, gb), a_g, coef.to(DEV), w_tail.to(DEV), dw_g, db_g, dgw_g, dgb_g, dx_g)
+    close("d1d_bwd.dx", dx_g, dx_w, rtol=2e-5)
+    for i in range(3):
+        close(f"d1d_bwd.cw{i}", dw_g[i], dw_w[i], rtol=2e-5)
+        close(f"d1d_bwd.cb{i}", db_g[i], db_w[i], rtol=2e-5)
+        close(f"d1d_bwd.gw{i}", dgw_g[i], dgw_w[i], rtol=2e-5)
+        close(f"d1d_bwd.gb{i}", dgb_g[i], dgb_w[i], rtol=2e-5)
+
+
+def test_generator_small_ops(hip):
+    rng = np.random.default_rng(10)
+    N = 6
+    for Cs, Cl, Ls, act in [(64, 32, 4, 0), (16, 8, 16, 0), (8, 1, 32, 1), (8, 1, 32, 2)]:
+        y, w, x = rnd(rng, N, Cs, Ls), rnd(rng, Cs, Cl, 4, scale=0.2), rnd(rng, N, Cl, 2 * Ls)
+        want = torch.zeros(N, Cl, 2 * Ls, dtype=torch.float64)
+        REF.convt1d_up(*d64(y, w), want, act)
+        got = torch.zeros(N, Cl, 2 * Ls, device=DEV)
+        hip.convt1d_up(*gpu(y, w), got, act)
+        close("ct1d_up", got, want)
+        want = torch.zeros(N, Cs, Ls, dtype=torch.float64)
+        REF.convt1d_down(*d64(x, w), want)
+        got = torch.zeros(N, Cs, Ls, device=DEV)
+        hip.convt1d_down(*gpu(x, w), got)
+        close("ct1d_down", got, want)
+        want = torch.zeros(Cs, Cl, 4, dtype=torch.float64)
+        REF.convt1d_wgrad(*d64(y, x), want)
+        got = torch.zeros(Cs, Cl, 4, device=DEV)
+        hip.convt1d_wgrad(*gpu(y, x), got)
+        close("ct1d_wgrad", got, want)
+    z, w1, da = rnd(rng, N, 128), rnd(rng, 128, 8192, scale=0.1), rnd(rng, N, 8192)
+    want, got = torch.zeros(N, 8192, dtype=torch.float64), torch.zeros(N, 8192, device=DEV)
+    REF.gemm_nn(*d64(z, w1), want)
+    hip.gemm_nn(*gpu(z, w1), got)
+    close("gemm_nn", got, want)
+    want, got = torch.zeros(128, 8192, dtype=torch.float64), torch.zeros(128, 8192, device=DEV)
+    REF.gemm_tn(*d64(z, da), want)
+    hip.gemm_tn(*gpu(z, da), got)
+    close("gemm_tn", got, want)

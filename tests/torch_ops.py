@@ -226,11 +226,6 @@ class TorchOps:
         else:
             dx.copy_(dy * (1 - y * y))
 
-    def convt1d_s1(self, z, w, y):
-        """First 1-D generator layer: ConvTranspose1d(k4, s1, p0) on a length-1 input =
-        y[b, co, k] = sum_ci z[b, ci] w[ci, co, k]."""
-        y.copy_(F.conv_transpose1d(z.view(z.shape[0], -1, 1), w))
-
     def convt1d_up(self, y, w, x, act=0):
         o = F.conv_transpose1d(y, w, None, stride=2, padding=1)
         if act == 1:
