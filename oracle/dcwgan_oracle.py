@@ -148,8 +148,21 @@ def synthetic_alignments(n: int, seed: int, size: int = DATA) -> Tuple[Tensor, T
 # forward passes
 # ----------------------------------------------------------------------------------------
 
+def _lrelu(x: Tensor, key: str, masks: Optional[Dict[str, Tensor]]) -> Tensor:
+    """LeakyReLU(0.1).  When `masks` holds `key`, the slope pattern (1 or 0.1 per element) is taken
+    from there instead of from sign(x): two fp32 implementations can disagree about the sign of a
+    pre-activation that is within rounding of 0, which changes no forward value (LeakyReLU is
+    continuous) but moves every gradient by O(1e-4); parity tests therefore evaluate the oracle on
+    the linear region the implementation under test actually took, and check separately that the
+    regions differ only at such ambiguous elements."""
+    if masks is not None and key in masks:
+        return x * masks[key].to(x.dtype)
+    return F.leaky_relu(x, SLOPE)
+
+
 def gen_forward(p: ParamDict, buf: Optional[ParamDict], z: Tensor, act: str = "sigmoid",
-                acts: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+                acts: Optional[Dict[str, Tensor]] = None, masks: Optional[Dict[str, Tensor]] = None
+                ) -> Tuple[Tensor, Tensor]:
     """layers.py:143-147.  BatchNorm always in training mode (the trainer never calls .eval(),
     src/train_wgan_v2.py:479,687): batch statistics normalise, running stats are updated with
     momentum 0.1 and the unbiased variance, num_batches_tracked += 1.  `buf` is updated in
@@ -171,7 +184,7 @@ def gen_forward(p: ParamDict, buf: Optional[ParamDict], z: Tensor, act: str = "s
         if acts is not None:
             acts[f"g2d.conv{i}"] = x
         if i < 4:
-            x = F.leaky_relu(bn(x, "twod_conv_layers", 3 * i + 1), SLOPE)
+            x = _lrelu(bn(x, "twod_conv_layers", 3 * i + 1), f"g2d.{i}", masks)
             if acts is not None:
                 acts[f"g2d.act{i}"] = x
     xs = final(x)
@@ -180,15 +193,15 @@ def gen_forward(p: ParamDict, buf: Optional[ParamDict], z: Tensor, act: str = "s
         w = p[f"oned_conv_layers.{3 * i}.weight"]
         y = F.conv_transpose1d(y, w, None, stride=1 if i == 0 else 2, padding=0 if i == 0 else 1)
         if i < 4:
-            y = F.leaky_relu(bn(y, "oned_conv_layers", 3 * i + 1), SLOPE)
+            y = _lrelu(bn(y, "oned_conv_layers", 3 * i + 1), f"g1d.{i}", masks)
             if acts is not None:
                 acts[f"g1d.act{i}"] = y
     xp = final(y)
     return xs, xp
 
 
-def disc_forward(p: ParamDict, xs: Tensor, xp: Tensor,
-                 acts: Optional[Dict[str, Tensor]] = None) -> Tensor:
+def disc_forward(p: ParamDict, xs: Tensor, xp: Tensor, acts: Optional[Dict[str, Tensor]] = None,
+                 masks: Optional[Dict[str, Tensor]] = None, tag: str = "d") -> Tensor:
     """layers.py:487-493: 4x[Conv2d k4 s2 p1 no bias, GroupNorm(1,C), LeakyReLU 0.1], flatten;
     3x[Conv1d k4 bias, GroupNorm(1,C), LeakyReLU], flatten; cat; Linear(11712,1)."""
     x = xs
@@ -197,16 +210,16 @@ def disc_forward(p: ParamDict, xs: Tensor, xp: Tensor,
         if acts is not None:
             acts[f"d2d.conv{i}"] = x
         x = F.group_norm(x, 1, p[f"twod_conv_layers.{3 * i + 1}.weight"], p[f"twod_conv_layers.{3 * i + 1}.bias"], GN_EPS)
-        x = F.leaky_relu(x, SLOPE)
+        x = _lrelu(x, f"{tag}.{i}", masks)
         if acts is not None:
-            acts[f"d2d.act{i}"] = x
+            acts[f"{tag}2d.act{i}"] = x
     y = xp
     for i in range(3):
         y = F.conv1d(y, p[f"oned_conv_layers.{3 * i}.weight"], p[f"oned_conv_layers.{3 * i}.bias"])
         y = F.group_norm(y, 1, p[f"oned_conv_layers.{3 * i + 1}.weight"], p[f"oned_conv_layers.{3 * i + 1}.bias"], GN_EPS)
         y = F.leaky_relu(y, SLOPE)
         if acts is not None:
-            acts[f"d1d.act{i}"] = y
+            acts[f"{tag}1d.act{i}"] = y
     feat = torch.cat([x.flatten(1), y.flatten(1)], dim=-1)
     return F.linear(feat, p["out.weight"], p["out.bias"])
 
@@ -216,7 +229,8 @@ def disc_forward(p: ParamDict, xs: Tensor, xp: Tensor,
 # ----------------------------------------------------------------------------------------
 
 def gp_penalty(p: ParamDict, real_s: Tensor, real_p: Tensor, fake_s: Tensor, fake_p: Tensor,
-               lam: float, t: Tensor, aux: Optional[Dict[str, Tensor]] = None) -> Tensor:
+               lam: float, t: Tensor, aux: Optional[Dict[str, Tensor]] = None,
+               masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """layers.py:34-55.  `t` is the (B,1,1,1) interpolation draw the reference takes from
     np.random.random (line 37).  The interpolates are detached leaves (lines 44-45); only the
     sites gradient is kept (`[0]`, line 53); `norm(2, dim=1)` runs over the size-1 channel
@@ -224,7 +238,7 @@ def gp_penalty(p: ParamDict, real_s: Tensor, real_p: Tensor, fake_s: Tensor, fak
     xi = (t * real_s + (1 - t) * fake_s).detach().requires_grad_(True)
     t1 = t[:, :, :, 0]
     pi = (t1 * real_p + (1 - t1) * fake_p).detach().requires_grad_(True)
-    out = disc_forward(p, xi, pi)
+    out = disc_forward(p, xi, pi, acts, masks, "d_gp")
     g = torch.autograd.grad(out, [xi, pi], torch.ones_like(out), create_graph=True, retain_graph=True)[0]
     if aux is not None:
         aux["interp_sites"] = xi.detach()
@@ -254,7 +268,8 @@ def _leafify(p: ParamDict) -> ParamDict:
 
 def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_s: Tensor, real_p: Tensor,
                  z: Tensor, loss: str = "gp", lam: float = 10.0, t: Optional[Tensor] = None,
-                 act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None
+                 act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None,
+                 masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None
                  ) -> Tuple[Tensor, ParamDict]:
     """One critic loss + its gradient w.r.t. every discriminator parameter
     (src/train_wgan_v2.py:534-609).  The generator forward runs in training mode and updates
@@ -262,17 +277,17 @@ def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_
     which only fills generator .grad fields that are zeroed before use, lines 538-539,619)."""
     B = real_s.size(0)
     with torch.no_grad():
-        fake_s, fake_p = gen_forward(gp_, gbuf, z, act)
+        fake_s, fake_p = gen_forward(gp_, gbuf, z, act, acts, masks)
     P = _leafify(dp)
     if loss == "div":
         real_s = real_s.detach().clone().requires_grad_(True)
         real_p = real_p.detach().clone().requires_grad_(True)
         fake_s = fake_s.detach().clone().requires_grad_(True)
         fake_p = fake_p.detach().clone().requires_grad_(True)
-    d = disc_forward(P, torch.cat([real_s, fake_s]), torch.cat([real_p, fake_p]))
+    d = disc_forward(P, torch.cat([real_s, fake_s]), torch.cat([real_p, fake_p]), acts, masks, "d_main")
     d_real, d_fake = d[:B], d[B:]
     if loss == "gp":
-        pen = gp_penalty(P, real_s, real_p, fake_s, fake_p, lam, t, aux)
+        pen = gp_penalty(P, real_s, real_p, fake_s, fake_p, lam, t, aux, masks, acts)
     elif loss == "div":
         pen = div_penalty(d_real, d_fake, real_s, real_p, fake_s, fake_p)
     else:
@@ -288,12 +303,13 @@ def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_
 
 
 def generator_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], z: Tensor,
-                    act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None
+                    act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None,
+                    masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None
                     ) -> Tuple[Tensor, ParamDict]:
     """src/train_wgan_v2.py:619-633: loss = -mean(D(G(z))), gradient w.r.t. generator params."""
     P = _leafify(gp_)
-    xs, xp = gen_forward(P, gbuf, z, act)
-    loss = -disc_forward(dp, xs, xp).mean()
+    xs, xp = gen_forward(P, gbuf, z, act, acts, masks)
+    loss = -disc_forward(dp, xs, xp, acts, masks, "d_main").mean()
     names = list(P.keys())
     grads = torch.autograd.grad(loss, [P[n] for n in names])
     if aux is not None:
@@ -322,6 +338,18 @@ class AdamState:
             self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
             denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
+
+
+def kink_margin(acts: Dict[str, Tensor]) -> float:
+    """Smallest |LeakyReLU output| relative to that tensor's rms over every recorded activation:
+    how far the nearest pre-activation is from the kink at 0, in units of the activation scale."""
+    m = float("inf")
+    for k, v in acts.items():
+        if ".act" not in k:
+            continue
+        rms = float(v.detach().double().pow(2).mean().sqrt())
+        m = min(m, float(v.detach().abs().min()) / max(rms, 1e-300))
+    return m
 
 
 def train_iteration(dp: ParamDict, gp_: ParamDict, gbuf: ParamDict, d_opt: AdamState, g_opt: AdamState,

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
     }
 }
 
-bool gn_shape_ok(int N, int C, int HW) { return N > 0 && C > 0 && C <= 512 && HW >= 16 && (HW & (HW - 1)) == 0; }
+bool gn_shape_ok(int N, int C, int HW) {
+    return N > 0 && C > 0 && C <= 512 && HW >= 16 && (HW & (HW - 1)) == 0 && (C * HW) % (4 * NT) == 0;
+}
 
 }  // namespace
 

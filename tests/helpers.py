@@ -27,19 +27,20 @@ def summary(t: torch.Tensor, nsamp: int = 256):
     return np.array([a.sum(), (a * a).sum()], dtype=np.float64), samp
 
 
-def check_summary(gold, name: str, t: torch.Tensor, rtol: float = RTOL, what: str = ""):
+def check_summary(gold, name: str, t: torch.Tensor, rtol: float = RTOL, what: str = "", atol: float = 0.0):
     """Compare tensor `t` against the (sum, sumsq, strided samples) the fixture holds for `name`.
-    Sampled values must agree to rtol relative to the tensor's RMS (norm-wise), the sum of
-    squares to 2*rtol-ish relative, the plain sum to rtol * sqrt(n * sumsq) (its natural scale)."""
+    Sampled values must agree to 4*rtol relative to the tensor's RMS (norm-wise) plus atol, the sum
+    of squares and the plain sum to the bounds those per-element errors imply."""
     stat, samp = summary(t)
     gstat, gsamp = gold[name + "#stat"], gold[name + "#samp"]
     n = t.numel()
     rms = float(np.sqrt(max(gstat[1], 1e-300) / n))
     err = float(np.max(np.abs(samp.astype(np.float64) - gsamp.astype(np.float64)))) if samp.size else 0.0
-    assert err <= rtol * max(rms, 1e-30) * 4 + 1e-12, f"{what}{name}: sample err {err:.3e} vs rms {rms:.3e}"
-    assert abs(stat[1] - gstat[1]) <= 4 * rtol * gstat[1] + 1e-20, f"{what}{name}: sumsq {stat[1]} vs {gstat[1]}"
+    assert err <= rtol * max(rms, 1e-30) * 4 + atol + 1e-12, f"{what}{name}: sample err {err:.3e} vs rms {rms:.3e}"
+    tol2 = 4 * rtol * gstat[1] + 2 * atol * np.sqrt(n * gstat[1]) + n * atol * atol + 1e-20
+    assert abs(stat[1] - gstat[1]) <= tol2, f"{what}{name}: sumsq {stat[1]} vs {gstat[1]}"
     scale = np.sqrt(n * max(gstat[1], 1e-300))
-    assert abs(stat[0] - gstat[0]) <= rtol * scale + 1e-12, f"{what}{name}: sum {stat[0]} vs {gstat[0]}"
+    assert abs(stat[0] - gstat[0]) <= rtol * scale + n * atol + 1e-12, f"{what}{name}: sum {stat[0]} vs {gstat[0]}"
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
