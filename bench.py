@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused DCWGAN-GP training step on MI355X.
+
+One "step" = one full iteration of the reference trainer's inner loop
+(/root/reference/src/train_wgan_v2.py:516-634): critic_iter (5) critic updates + 1 generator
+update at batch 64 per GPU, gp loss, sigmoid generator (BASELINE.json configs[1]).  Inputs are
+synthetic ms-style 64x64 alignments resident in HBM before the timed region; z and t are drawn on
+the device.  Metric: train alignments/sec = critic_iter * global_batch * steps / wall time.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (fp32 MFMA implicit-GEMM
+convolutions), timed with HIP events around its launches in an instrumented pass that follows the
+timed region; `cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step)
+on this box's host cores over a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pg-alignments-gan_amd"))
+
+import numpy as np
+import torch
+
+F_D = 204_593_664          # discriminator forward FLOP / sample
+F_G = 205_703_168          # generator forward FLOP / sample
+FLOP_PER_ALIGNMENT = {"gp": (5 * (F_G + 12 * F_D) + 3 * F_G + 2 * F_D) / 5.0}
+FLOP_PER_ALIGNMENT["div"] = FLOP_PER_ALIGNMENT["gp"]
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_pool(n, seed):
+    """ms-style synthetic alignments: every column polymorphic, derived-allele count ~ 1/i."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    size = 64
+    w = 1.0 / np.arange(1, size)
+    w /= w.sum()
+    counts = rng.choice(np.arange(1, size), size=(n, size), p=w)
+    rank = np.argsort(np.argsort(rng.random((n, size, size)), axis=1), axis=1)
+    sites = (rank < counts[:, None, :]).astype(np.float32)
+    pos = np.sort(rng.random((n, size)), axis=1).astype(np.float32)
+    return torch.from_numpy(sites[:, None]), torch.from_numpy(pos[:, None])
+
+
+class TimedOps:
+    """Proxy around HipOps that brackets the conv-family launches with HIP events on the launch
+    stream and accumulates (calls, flops, events) per kernel + shape."""
+    NAMES = ("conv_down", "conv_up", "conv_wgrad")
+
+    def __init__(self, ops):
+        self._ops = ops
+        self.records = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+        if name not in self.NAMES:
+            return fn
+
+        def timed(*a, **k):
+            if name == "conv_down":
+                x, w = a[0], a[1]
+                n, cs, cl, hs = x.shape[0], w.shape[0], w.shape[1], x.shape[2] // 2
+            elif name == "conv_up":
+                y, w = a[0], a[1]
+                n, cs, cl, hs = y.shape[0], w.shape[0], w.shape[1], y.shape[2]
+            else:
+                ya, x = a[0], a[1]
+                n, cs, cl, hs = ya.shape[0], ya.shape[1], x.shape[1], ya.shape[2]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn(*a, **k)
+            e.record()
+            key = (name, n, cs, cl, hs)
+            self.records.setdefault(key, []).append((s, e, 2.0 * n * cs * cl * 16 * hs * hs))
+        return timed
+
+    def summary(self):
+        out = {}
+        for key, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            out[key] = dict(calls=len(recs), ms=float(np.mean(ms)), total_ms=float(np.sum(ms)), flops=recs[0][2])
+        return out
+
+
+def cpu_baseline(loss, act, batch, critic_iter, iters=3):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dcwgan_oracle as orc
+    torch.manual_seed(0)
+    gp_ = orc.make_params(orc.gen_param_shapes(), 20261)
+    dp = orc.make_params(orc.disc_param_shapes(), 20262)
+    gbuf = orc.make_gen_buffers()
+    d_opt, g_opt = orc.AdamState(dp), orc.AdamState(gp_)
+    rs, rp = orc.synthetic_alignments(batch * critic_iter, 20263)
+    batches = [(rs[i * batch:(i + 1) * batch], rp[i * batch:(i + 1) * batch]) for i in range(critic_iter)]
+
+    def one():
+        zs = [torch.randn(batch, 128, 1, 1) for _ in range(critic_iter + 1)]
+        ts = [torch.rand(batch, 1, 1, 1) for _ in range(critic_iter)]
+        orc.train_iteration(dp, gp_, gbuf, d_opt, g_opt, batches, zs, ts if loss == "gp" else None, loss, 10.0, act)
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return dict(value=critic_iter * batch * iters / dt, unit="alignments/sec", cores=torch.get_num_threads(),
+                kind="port", sample=f"{iters} full iterations (5 critic + 1 generator step, batch {batch}) after 1 "
+                                     f"warm-up, stock-PyTorch CPU oracle, {dt / iters:.2f} s/iteration")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="batch per GPU")
+    ap.add_argument("--loss", default="gp", choices=["gp", "div"])
+    ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "tanh"])
+    ap.add_argument("--critic-iter", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=3, help="instrumented iterations for per-kernel timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+
+    ops = HipOps(dev)
+    timed = TimedOps(ops)
+    tr = FusedTrainer(timed, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
+                      seed=1234, process_group=pg, rank=rank, world=world)
+    from pgan_engine import disc_param_shapes, gen_param_shapes
+    gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
+    for store, shapes in ((tr.eng.G, gen_param_shapes()), (tr.eng.D, disc_param_shapes())):
+        for k, sh in shapes.items():
+            if len(sh) == 1:
+                v = torch.ones(sh) if k.endswith("weight") and not k.startswith("out") else torch.zeros(sh)
+            else:
+                fan = int(np.prod(sh[1:]))
+                v = (torch.rand(sh, generator=gen) * 2 - 1) / fan ** 0.5
+            store.p[k].copy_(v)
+    ps, pp = synthetic_pool(4096, 20260 + 1 + rank)
+    tr.set_pool(ps, pp, normalize=(args.act == "tanh"))
+
+    use_graph = (world == 1) and not args.no_graph
+    step = tr.iteration
+    if use_graph:
+        timed_names, TimedOps.NAMES = TimedOps.NAMES, ()     # no events inside the captured graph
+        tr.capture()
+        TimedOps.NAMES = timed_names
+        step = tr.replay
+    TimedOps.NAMES, saved = (), TimedOps.NAMES
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    losses = tr.losses()
+
+    # instrumented eager pass: HIP events around every conv-family launch
+    TimedOps.NAMES = saved
+    timed.records.clear()
+    for _ in range(args.profile_iters):
+        tr.iteration()
+    torch.cuda.synchronize()
+    summ = timed.summary()
+
+    if rank == 0:
+        fam = {}
+        for (name, n, cs, cl, hs), r in summ.items():
+            f = fam.setdefault(name, dict(total_ms=0.0, flops=0.0, calls=0))
+            f["total_ms"] += r["total_ms"]
+            f["flops"] += r["flops"] * r["calls"]
+            f["calls"] += r["calls"]
+        dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
+        roofline = None
+        if dom:
+            f = fam[dom]
+            ach = f["flops"] / (f["total_ms"] * 1e-3) / 1e12
+            per_shape = {f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]":
+                         dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
+                              tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in sorted(summ.items())}
+            roofline = dict(bound="mfma", kernel=f"{dom}_kernel (fp32 MFMA implicit GEMM)", achieved=round(ach, 3),
+                            peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                            traffic=None,
+                            avg_launch_us=round(f["total_ms"] * 1e3 / f["calls"], 2), launches=f["calls"],
+                            flops_per_launch_avg=f["flops"] / f["calls"],
+                            measured=f"HIP events on the launch stream, {args.profile_iters} instrumented iterations "
+                                     f"after the timed region", families={k: dict(
+                                         share_ms_per_iter=round(v["total_ms"] / args.profile_iters, 3),
+                                         tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2)) for k, v in fam.items()},
+                            per_shape=per_shape)
+        nalign = args.critic_iter * args.batch * world * args.steps
+        value = nalign / dt
+        out = dict(metric="train alignments/sec (WGAN-GP step, 64x64)", value=round(value, 2), unit="alignments/sec",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
+                                        f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
+                               global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,
+                               hip_graph=bool(use_graph), parallelism=f"dp{world}"),
+                   step_tflops=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12, 3),
+                   step_frac_of_fp32_mfma_peak=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+                   losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

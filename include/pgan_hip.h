@@ -102,6 +102,12 @@ int pgan_adam(float* p, const float* g, float* m, float* v, long long n, float l
  * (src/layers.py:37).  state: 4 uint32 on the device (seed lo, hi, offset lo, hi), advanced by the call. */
 int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStream_t st);
 
+/* Next B alignments (sites [.,1,64,64] = Ms floats, positions [.,1,64] = Mp floats) of a pool that is
+ * resident in HBM, wrapping at npool; the cursor is a device int advanced by the call.  Replaces the
+ * host loader's get_batch + .to(device) (src/train_wgan_v2.py:517,526-527) inside a captured step. */
+int pgan_take_batch(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool, int B,
+                    int Ms, int Mp, hipStream_t st);
+
 /* ---- discriminator 1-D tower, src/layers.py:470-480.  params: 12 device pointers
  * (conv w, conv b, gn w, gn b) x 3.  a1 [N][16][61], a2 [N][32][58], a3 [N][64][55] keep the conv
  * outputs for the backward; feat [N][3520]. */

@@ -217,6 +217,25 @@ __global__ void philox_advance_kernel(uint32_t* state, uint32_t groups) {
     state[3] = (uint32_t)(off >> 32);
 }
 
+// out_s[b] = pool_s[(cursor + b) % npool], same for positions; cursor lives in device memory.
+__global__ void take_batch_kernel(const float* __restrict__ pool_s, const float* __restrict__ pool_p,
+                                  float* __restrict__ out_s, float* __restrict__ out_p, const int* __restrict__ cursor,
+                                  int npool, int B, int Ms, int Mp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = cursor[0];
+    if (i < (int64_t)B * Ms / 4) {
+        const int b = (int)(i / (Ms / 4)), e = (int)(i % (Ms / 4));
+        const int src = (c0 + b) % npool;
+        reinterpret_cast<f32x4*>(out_s)[i] = reinterpret_cast<const f32x4*>(pool_s + (int64_t)src * Ms)[e];
+    }
+    if (i < (int64_t)B * Mp / 4) {
+        const int b = (int)(i / (Mp / 4)), e = (int)(i % (Mp / 4));
+        const int src = (c0 + b) % npool;
+        reinterpret_cast<f32x4*>(out_p)[i] = reinterpret_cast<const f32x4*>(pool_p + (int64_t)src * Mp)[e];
+    }
+}
+__global__ void cursor_advance_kernel(int* cursor, int npool, int B) { cursor[0] = (cursor[0] + B) % npool; }
+
 inline int grid_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -298,6 +317,15 @@ int pgan_adam(float* p, const float* g, float* m, float* v, long long n, float l
     if (n <= 0 || n % 4) return PGAN_EINVAL;
     if (step_dev) adam_tick_kernel<<<1, 1, 0, st>>>(step_dev);
     adam_kernel<<<grid_for(n / 4, 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, step_dev, step);
+    return pgan_launch_status();
+}
+
+// Next B alignments of a device-resident pool (wrapping), then cursor += B.
+int pgan_take_batch(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool, int B,
+                    int Ms, int Mp, hipStream_t st) {
+    if (B <= 0 || npool <= 0 || Ms % 4 || Mp % 4 || Mp > Ms) return PGAN_EINVAL;
+    take_batch_kernel<<<grid_for((int64_t)B * Ms / 4, 256), 256, 0, st>>>(pool_s, pool_p, out_s, out_p, cursor, npool, B, Ms, Mp);
+    cursor_advance_kernel<<<1, 1, 0, st>>>(cursor, npool, B);
     return pgan_launch_status();
 }
 

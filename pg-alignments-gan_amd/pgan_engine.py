@@ -242,7 +242,8 @@ class Engine:
         """(sites, positions) = G(z), BatchNorm in training mode (layers.py:143-147).  Activations
         stay in the generator workspace for a following gen_backward."""
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
-        self.Z.copy_(z.reshape(self.B, self.latent))
+        if z.data_ptr() != self.Z.data_ptr():
+            self.Z.copy_(z.reshape(self.B, self.latent))
         self.g_batches_tracked += 1
         o.gemm_nn(self.Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), self.gA[1].view(self.B, -1))
         for i in range(1, 5):
@@ -335,13 +336,21 @@ class Engine:
         """Loss W = mean D(fake) - mean D(real) + penalty and its gradient w.r.t. every
         discriminator parameter (into self.D.g, overwritten); self.closs = [W, mean real, mean
         fake, penalty].  `t` (B values in [0,1)) is the gp interpolation draw."""
-        o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
-        Dp, Dg = self.D.p, self.D.g
+        B = self.B
         self.X0[:B].copy_(real_s)
         self.P0[:B].copy_(real_p)
-        self.gen_forward(z, self.X0[B:2 * B], self.P0[B:2 * B])
+        self.Z.copy_(z.reshape(B, self.latent))
         if self.loss == "gp":
             self.tbuf.copy_(t.reshape(B))
+        self.critic_grads_resident()
+
+    def critic_grads_resident(self) -> None:
+        """critic_grads on inputs already placed in the workspace: real batch in X0[:B] / P0[:B],
+        z in Z, t in tbuf."""
+        o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
+        Dp, Dg = self.D.p, self.D.g
+        self.gen_forward(self.Z, self.X0[B:2 * B], self.P0[B:2 * B])
+        if self.loss == "gp":
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
         # primal forward
         self._d_forward2d(0, NS)
@@ -404,9 +413,14 @@ class Engine:
     def generator_grads(self, z: torch.Tensor) -> None:
         """loss = -mean D(G(z)) and its gradient w.r.t. the generator parameters (self.G.g);
         self.gloss holds the loss (src/train_wgan_v2.py:619-633)."""
+        self.Z.copy_(z.reshape(self.B, self.latent))
+        self.generator_grads_resident()
+
+    def generator_grads_resident(self) -> None:
+        """generator_grads with z already in self.Z."""
         o, B = self.ops, self.B
         Dp = self.D.p
-        self.gen_forward(z, self.gXs, self.gXp)
+        self.gen_forward(self.Z, self.gXs, self.gXp)
         self.X0[:B].copy_(self.gXs)
         self.P0[:B].copy_(self.gXp)
         self._d_forward2d(0, B)
@@ -425,15 +439,24 @@ class Engine:
         self.adam_g()
 
     # ------------------------------------------------------------------------------------------
+    def use_device_step_counters(self) -> None:
+        """Keep Adam's step counts in device memory (needed before capturing steps in a graph)."""
+        self.D.step_dev = torch.full((1,), self.D.step, dtype=torch.int32, device=self.dev)
+        self.G.step_dev = torch.full((1,), self.G.step, dtype=torch.int32, device=self.dev)
+
+    def _adam(self, st: FlatStore, lr: float) -> None:
+        st.step += 1
+        if getattr(st, "step_dev", None) is not None:
+            self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, 0, lr, self.betas[0], self.betas[1], self.eps,
+                          st.step_dev)
+        else:
+            self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, st.step, lr, self.betas[0], self.betas[1], self.eps)
+
     def adam_d(self) -> None:
-        self.D.step += 1
-        self.ops.adam(self.D.flat, self.D.gflat, self.D.mflat, self.D.vflat, self.D.step, self.lr_d,
-                      self.betas[0], self.betas[1], self.eps)
+        self._adam(self.D, self.lr_d)
 
     def adam_g(self) -> None:
-        self.G.step += 1
-        self.ops.adam(self.G.flat, self.G.gflat, self.G.mflat, self.G.vflat, self.G.step, self.lr_g,
-                      self.betas[0], self.betas[1], self.eps)
+        self._adam(self.G, self.lr_g)
 
     def train_iteration(self, real_batches: List[Tuple[torch.Tensor, torch.Tensor]], zs: List[torch.Tensor],
                         ts: Optional[List[torch.Tensor]] = None) -> None:

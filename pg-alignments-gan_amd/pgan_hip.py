@@ -55,6 +55,7 @@ _SIGS = {
     "pgan_affine": [P, P, L, F, F, P],
     "pgan_adam": [P, P, P, P, L, F, F, F, F, P, I, P],
     "pgan_philox": [P, L, P, I, P],
+    "pgan_take_batch": [P, P, P, P, P, I, I, I, I, P],
     "pgan_d1d_fwd": [P, P, P, P, P, P, I, P],
     "pgan_d1d_bwd": [P, P, P, P, P, P, P, P, I, P, P, I, P],
     "pgan_ct1d_up": [P, P, P, I, I, I, I, I, P],
@@ -228,6 +229,11 @@ class HipOps:
 
     def philox(self, out, state, normal: bool):
         _check(_lib.pgan_philox(_ptr(out), out.numel(), state.data_ptr(), int(normal), _stream()), "pgan_philox")
+
+    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor):
+        B = out_s.shape[0]
+        _check(_lib.pgan_take_batch(_ptr(pool_s), _ptr(pool_p), _ptr(out_s), _ptr(out_p), cursor.data_ptr(),
+                                    pool_s.shape[0], B, out_s[0].numel(), out_p[0].numel(), _stream()), "pgan_take_batch")
 
     # ---------------- discriminator 1-D tower ----------------
     @staticmethod

@@ -1,0 +1,106 @@
+"""FusedTrainer: the whole critic_iter loop + generator step of PG-Alignments-GAN's trainer
+(/root/reference/src/train_wgan_v2.py:516-634) as one sequence of HIP kernel launches on static
+buffers, optionally captured into a hipGraph and replayed.
+
+Inside one iteration nothing touches the host: real batches come from a pool resident in HBM
+(pgan_take_batch), z ~ N(0,1) and t ~ U[0,1) from device-side Philox state, Adam's step counts live
+in device memory, and the losses stay in device buffers until the caller reads them.
+
+Data parallel (one process per GPU, torch.distributed with the RCCL backend): every rank holds full
+replicas of both networks and optimiser states, draws its own batch / z / t, and the flat gradient
+buffers are all-reduced (mean) before each Adam step.  BatchNorm statistics stay per rank.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from pgan_engine import Engine
+
+
+class FusedTrainer:
+    def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
+                 critic_iter: int = 5, seed: int = 1234, lr_d: float = 5e-5, lr_g: float = 5e-5,
+                 latent: int = 128, process_group=None, rank: int = 0, world: int = 1):
+        self.ops, self.dev, self.critic_iter = ops, device, int(critic_iter)
+        self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g)
+        self.eng.use_device_step_counters()
+        self.rank, self.world, self.pg = rank, world, process_group
+        # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks differ in the seed's high word
+        self.rng_z = torch.tensor([seed & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
+        self.rng_t = torch.tensor([(seed + 1) & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        self.pool_s: Optional[torch.Tensor] = None
+        self.pool_p: Optional[torch.Tensor] = None
+        self.graph = None
+        self.iterations = 0
+
+    def set_pool(self, sites: torch.Tensor, pos: torch.Tensor, normalize: bool = False) -> None:
+        """Real alignments resident on the device: sites [P,1,64,64], positions [P,1,64], fp32.
+        normalize applies (x - 0.5) / 0.5 once here (src/train_wgan_v2.py:453,519-521)."""
+        assert sites.shape[0] == pos.shape[0] and sites.shape[0] >= self.eng.B
+        self.pool_s = sites.to(self.dev, torch.float32).contiguous().clone()
+        self.pool_p = pos.to(self.dev, torch.float32).contiguous().clone()
+        if normalize:
+            self.ops.affine(self.pool_s, 2.0, -1.0, self.pool_s)
+            self.ops.affine(self.pool_p, 2.0, -1.0, self.pool_p)
+        self.cursor.zero_()
+
+    def _allreduce(self, flat: torch.Tensor) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
+
+    def _iteration_body(self) -> None:
+        e, o = self.eng, self.ops
+        B = e.B
+        for _ in range(self.critic_iter):
+            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
+            o.philox(e.Z, self.rng_z, True)
+            if e.loss == "gp":
+                o.philox(e.tbuf, self.rng_t, False)
+            e.critic_grads_resident()
+            self._allreduce(e.D.gflat)
+            e.adam_d()
+        o.philox(e.Z, self.rng_z, True)
+        e.generator_grads_resident()
+        self._allreduce(e.G.gflat)
+        e.adam_g()
+
+    def iteration(self) -> None:
+        """One full iteration, launched eagerly on the current stream."""
+        self._iteration_body()
+        self.iterations += 1
+
+    def capture(self) -> None:
+        """Record one iteration into a hipGraph (single-GPU path; every launch is on static buffers)."""
+        if self.world > 1:
+            raise RuntimeError("graph capture is used on the single-GPU path only")
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):     # one eager pass on the capture stream warms every kernel
+            self._iteration_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.iterations += 1
+        tracked, dstep, gstep = self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._iteration_body()
+        # capture records launches without running them: undo the host-side counters it bumped
+        self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step = tracked, dstep, gstep
+
+    def replay(self) -> None:
+        self.graph.replay()
+        self.iterations += 1
+        self.eng.g_batches_tracked += self.critic_iter + 1
+        self.eng.D.step += self.critic_iter
+        self.eng.G.step += 1
+
+    def losses(self):
+        """(critic loss W, mean real, mean fake, penalty, generator loss) of the last step: one D2H read."""
+        c = self.eng.closs.tolist()
+        return c[0], c[1], c[2], c[3], float(self.eng.gloss)
