@@ -22,6 +22,10 @@ extern "C" {
  * S[N][Cs][hs][hs] and a large side L[N][Cl][2hs][2hs].  Cl > 1: fp32 MFMA implicit GEMM
  * (Cs % 64 == 0, Cl % 64 == 0 for up / % 8 for down and wgrad, hs in {4, 8, 16}); Cl == 1: hs == 32, Cs <= 64. */
 
+/* Kernel-variant overrides for tuning runs (no counterpart in the reference): "down_kg" = 1|2|4 K groups
+ * of the DOWN kernel, "up_mode" = 1 all-phase tiles | 2 phase-split | 3 phase-split + 2 K groups; 0 = auto. */
+int pgan_set_option(const char* name, int value);
+
 /* S = conv2d(L, W, stride 2, pad 1): nn.Conv2d forward, src/layers.py:441-463 (discriminator);
  * input-gradient of nn.ConvTranspose2d, src/layers.py:97-112 (generator backward). */
 int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);

@@ -42,9 +42,9 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // ------------------------------------------------------------------------------------------------
 // DOWN: GEMM M = Cs (BM per block), N = pixels (BN per block), K = Cl*16 (CLC channels per step)
 // ------------------------------------------------------------------------------------------------
-template <int HS, int BM, int BN, int CLC>
-__global__ __launch_bounds__(256) void conv_down_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                        float* __restrict__ Y, int N, int Cs, int Cl) {
+template <int HS, int BM, int BN, int CLC, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_down_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                             float* __restrict__ Y, int N, int Cs, int Cl) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -54,12 +54,17 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const float* __restrict_
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
     constexpr int AV = BM * CLC * 4 / 256;
+    constexpr int GRP = BM * ALD + CLC * CHS;            // LDS floats of one K group
     static_assert(BM % 64 == 0 && BN % 64 == 0 && AV >= 1, "tile shape");
-    __shared__ __attribute__((aligned(16))) float lds[BM * ALD + CLC * CHS];
-    float* As = lds;
-    float* Bs = lds + BM * ALD;
+    static_assert(KG == 1 || GRP * KG >= (KG - 1) * 4 * TM * TN * 16 * 64, "reduction scratch must fit");
+    __shared__ __attribute__((aligned(16))) float lds[GRP * KG];
+    // K is split over KG groups of 4 waves; each group stages and multiplies its own channels and
+    // the partial tiles are summed through LDS at the end.
+    const int grp = threadIdx.x >> 8;
+    float* As = lds + grp * GRP;
+    float* Bs = As + BM * ALD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
     const int nmt = Cs / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
@@ -124,12 +129,12 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    const int nk = Cl / CLC;
-    gload(0);
+    const int nk = Cl / (CLC * KG);
+    gload(grp * CLC);
     for (int kc = 0; kc < nk; ++kc) {
         lstore();
         __syncthreads();
-        if (kc + 1 < nk) gload((kc + 1) * CLC);
+        if (kc + 1 < nk) gload(((kc + 1) * KG + grp) * CLC);
 #pragma unroll
         for (int c = 0; c < CLC; ++c)
 #pragma unroll
@@ -156,6 +161,30 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const float* __restrict_
                     }
             }
         __syncthreads();
+    }
+
+    if (KG > 1) {   // sum the K groups' partial tiles: groups 1.. park theirs in LDS, group 0 adds
+        float* red = lds + ((grp - 1) * 4 + wave) * (TM * TN * 16 * 64) + lane;
+        if (grp > 0) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((tm * TN + tn) * 16 + r) * 64] = acc[tm][tn][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float* src = lds + ((g - 1) * 4 + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += src[((tm * TN + tn) * 16 + r) * 64];
+        }
     }
 
 #pragma unroll
@@ -316,6 +345,143 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const float* __restrict__ 
                 *reinterpret_cast<float2*>(o) = make_float2(acc[tm][tn][0][r], acc[tm][tn][1][r]);
                 *reinterpret_cast<float2*>(o + WL) = make_float2(acc[tm][tn][2][r], acc[tm][tn][3][r]);
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UP, phase-split form for launches that would otherwise leave SIMDs idle: block tile = 32 cl x 32
+// S-grid pixels, wave p of a group computes sub-pixel phase p only (one accumulator tile, K = Cs*4),
+// and K (cs) may additionally be split over KG groups of 4 waves that are summed through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int HS, int CSC, int KG>
+__global__ __launch_bounds__(256 * KG) void conv_up_ps_kernel(const float* __restrict__ Y, const float* __restrict__ W,
+                                                              float* __restrict__ X, int N, int Cs, int Cl) {
+    constexpr int BM = 32, BN = 32;
+    using T = PixTile<HS, BN>;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
+    constexpr int SEG = T::SEG, R = T::R;
+    constexpr int PR = R + 2, PC = WS + 2, PCP = PC | 1;
+    constexpr int CHS = SEG * PR * PCP;
+    constexpr int ALD = BM + 1;
+    constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
+    constexpr int AV = CSC * BM * 4 / 256;
+    constexpr int GRP = CSC * 16 * ALD + CSC * CHS;
+    static_assert(CSC % 2 == 0 && AV >= 1, "tile shape");
+    static_assert(KG == 1 || GRP * KG >= (KG - 1) * 4 * 16 * 64, "reduction scratch must fit");
+    __shared__ __attribute__((aligned(16))) float lds[GRP * KG];
+    const int grp = threadIdx.x >> 8;
+    float* As = lds + grp * GRP;
+    float* Bs = As + CSC * 16 * ALD;
+
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int ph = wave >> 1, pw = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nmt = Cl / BM, npt = T::ntiles(N);
+    const int b = xcd_remap(blockIdx.x, nmt * npt);
+    const int ptile = b / nmt, cl0 = (b % nmt) * BM;
+    int n0, oh0;
+    T::origin(ptile, n0, oh0);
+
+    int64_t poff[NQ];
+    int loff[NQ];
+    bool pval[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        const int seg = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+        const int n = n0 + seg, a = oh0 - 1 + pr, bb = pc - 1;
+        pval[q] = (e < PE) && n < N && a >= 0 && a < HS && bb >= 0 && bb < WS;
+        poff[q] = ((int64_t)n * Cs * HS + a) * WS + bb;
+        loff[q] = (e < PE) ? (seg * PR + pr) * PCP + pc : -1;
+    }
+    f32x4 areg[AV];
+    float breg[CSC][NQ];
+    auto gload = [&](int cs0) {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, csl = idx / (BM * 4), rem = idx % (BM * 4);
+            areg[q] = *reinterpret_cast<const f32x4*>(W + ((int64_t)(cs0 + csl) * Cl + cl0) * 16 + rem * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < CSC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                breg[c][q] = pval[q] ? Y[poff[q] + (int64_t)(cs0 + c) * HS * WS] : 0.f;
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int idx = tid + 256 * q, csl = idx / (BM * 4), rem = idx % (BM * 4);
+            const int cll = rem / 4, t4 = rem % 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(csl * 16 + t4 * 4 + e) * ALD + cll] = areg[q][e];
+        }
+#pragma unroll
+        for (int c = 0; c < CSC; ++c)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (loff[q] >= 0) Bs[c * CHS + loff[q]] = breg[c][q];
+    };
+
+    // this wave's 4 taps: rows kh in {1,3} (ph 0) or {2,0} (ph 1) reading S rows a+{0,-1} / a+{0,+1}
+    int aoff[4], boff[4];
+    const int seg = j / (R * WS), al = (j % (R * WS)) / WS, bl = j % WS;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw) {
+            const int kh = ph ? (th ? 0 : 2) : (th ? 3 : 1), dh = ph ? th : -th;
+            const int kw = pw ? (tw ? 0 : 2) : (tw ? 3 : 1), dw = pw ? tw : -tw;
+            aoff[th * 2 + tw] = (kh * 4 + kw) * ALD + j;
+            boff[th * 2 + tw] = (seg * PR + al + 1 + dh) * PCP + bl + 1 + dw;
+        }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int nk = Cs / (CSC * KG);
+    gload(grp * CSC);
+    for (int kc = 0; kc < nk; ++kc) {
+        lstore();
+        __syncthreads();
+        if (kc + 1 < nk) gload(((kc + 1) * KG + grp) * CSC);
+#pragma unroll
+        for (int g = 0; g < CSC / 2; ++g) {
+            const int csl = 2 * g + h;
+            float a[4], bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[csl * 16 * ALD + aoff[t]];
+                bv[t] = Bs[csl * CHS + boff[t]];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv[t], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (KG > 1) {
+        float* red = lds + ((grp - 1) * 4 + wave) * (16 * 64) + lane;
+        if (grp > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float* src = lds + ((g - 1) * 4 + wave) * (16 * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += src[r * 64];
+        }
+    }
+
+    const int n = n0 + seg;
+    if (n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = cl0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            X[(((int64_t)n * Cl + cl) * HL + 2 * (oh0 + al) + ph) * WL + 2 * bl + pw] = acc[r];
+        }
     }
 }
 
@@ -604,30 +770,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_c1_kernel(const float* __restr
         }
 }
 
-__global__ void rows_sum_kernel(const float* __restrict__ part, int ld, float* __restrict__ out, int C, int r0, int r1,
-                                int r2, int r3, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_r coef[r] * part[r * ld + c] over rows [r0, r1) and [r2, r3) (coef == nullptr: 1).
+// Block = 32 columns x 8 row lanes; rows are strided over the lanes and combined through LDS.
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int ld,
+                                                       const float* __restrict__ coef, float* __restrict__ out, int C,
+                                                       int r0, int r1, int r2, int r3, int accumulate) {
+    __shared__ float sh[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += part[(int64_t)r * ld + c];
-    for (int r = r2; r < r3; ++r) s += part[(int64_t)r * ld + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C) {
+        for (int r = r0 + ry; r < r1; r += 8) s = fmaf(coef ? coef[r] : 1.f, part[(int64_t)r * ld + c], s);
+        for (int r = r2 + ry; r < r3; r += 8) s = fmaf(coef ? coef[r] : 1.f, part[(int64_t)r * ld + c], s);
+    }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
+
+// wave tiles (32 x 32 outputs each) a launch should reach before it stops splitting K: two per SIMD
+constexpr int FILL_WAVES = 2048;
+// tuning overrides (0 = choose from the launch size): see pgan_set_option
+int g_down_kg = 0;     // 1, 2, 4: K groups of the DOWN kernel
+int g_up_mode = 0;     // 1: all-phase 64x64 tiles; 2: phase-split, no K split; 3: phase-split, 2 K groups
 
 template <int HS>
 int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl, hipStream_t st) {
-    constexpr int BM = 64, BN = 64, CLC = 8;
-    if (Cs % BM || Cl % CLC) return PGAN_EINVAL;
+    constexpr int BM = 64, BN = 64;
+    if (Cs % BM || Cl % 16) return PGAN_EINVAL;
     const int grid = (Cs / BM) * PixTile<HS, BN>::ntiles(N);
-    conv_down_kernel<HS, BM, BN, CLC><<<grid, 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+    const int waves = grid * 4;
+    const int kg = g_down_kg ? g_down_kg : (waves >= FILL_WAVES ? 1 : (waves * 2 >= FILL_WAVES ? 2 : 4));
+    if (kg == 1) conv_down_kernel<HS, BM, BN, 8, 1><<<grid, 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+    else if (kg == 2) conv_down_kernel<HS, BM, BN, 4, 2><<<grid, 512, 0, st>>>(X, W, Y, N, Cs, Cl);
+    else conv_down_kernel<HS, BM, BN, 4, 4><<<grid, 1024, 0, st>>>(X, W, Y, N, Cs, Cl);
     return pgan_launch_status();
 }
 template <int HS>
 int launch_up(const float* Y, const float* W, float* X, int N, int Cs, int Cl, hipStream_t st) {
     constexpr int BM = 64, BN = 64, CSC = 8;
-    if (Cl % BM || Cs % CSC) return PGAN_EINVAL;
+    if (Cl % BM || Cs % 32) return PGAN_EINVAL;
     const int grid = (Cl / BM) * PixTile<HS, BN>::ntiles(N);
-    conv_up_kernel<HS, BM, BN, CSC><<<grid, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
+    const int grid_ps = (Cl / 32) * PixTile<HS, 32>::ntiles(N);
+    int mode = g_up_mode;
+    if (!mode) mode = (grid * 4 >= 2 * FILL_WAVES) ? 1 : (grid_ps * 4 >= FILL_WAVES ? 2 : 3);
+    if (mode == 1) conv_up_kernel<HS, BM, BN, CSC><<<grid, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
+    else if (mode == 2) conv_up_ps_kernel<HS, 16, 1><<<grid_ps, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
+    else conv_up_ps_kernel<HS, 8, 2><<<grid_ps, 512, 0, st>>>(Y, W, X, N, Cs, Cl);
     return pgan_launch_status();
 }
 constexpr int WG_BM = 64, WG_CLB = 8, WG_PIXC = 64;
@@ -659,6 +853,17 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
 }  // namespace
 
 extern "C" {
+
+// Tuning overrides for experiments; 0 restores the size-based choice.  "down_kg": 1|2|4, "up_mode": 1|2|3.
+int pgan_set_option(const char* name, int value) {
+    if (!name) return PGAN_EINVAL;
+    const char* a = "down_kg";
+    const char* b = "up_mode";
+    auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
+    if (eq(name, a) && (value == 0 || value == 1 || value == 2 || value == 4)) { g_down_kg = value; return PGAN_OK; }
+    if (eq(name, b) && value >= 0 && value <= 3) { g_up_mode = value; return PGAN_OK; }
+    return PGAN_EINVAL;
+}
 
 // S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W[Cs,Cl,4,4], stride 2, pad 1).  H = hs.
 int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
@@ -714,7 +919,7 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
     if (Cl == 1) {
         if (hs != 32 || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
         conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
-        rows_sum_kernel<<<(Cs * 16 + 255) / 256, 256, 0, st>>>(ws, Cs * 16, dW, Cs * 16, 0, N, 0, 0, 0);
+        rows_sum_kernel<<<(Cs * 16 + 31) / 32, 256, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, 0);
         return pgan_launch_status();
     }
     switch (hs) {
@@ -729,7 +934,14 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
 int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r1, int r2, int r3, int accumulate,
                      hipStream_t st) {
     if (C <= 0 || ld < C) return PGAN_EINVAL;
-    rows_sum_kernel<<<(C + 255) / 256, 256, 0, st>>>(part, ld, out, C, r0, r1, r2, r3, accumulate);
+    rows_sum_kernel<<<(C + 31) / 32, 256, 0, st>>>(part, ld, nullptr, out, C, r0, r1, r2, r3, accumulate);
+    return pgan_launch_status();
+}
+
+// dw[j] = sum_n coef[n] * x[n * J + j]: weight gradient of the linear head and its bias.
+int pgan_head_wgrad(const float* x, const float* coef, float* dw, int N, int J, hipStream_t st) {
+    if (N <= 0 || J <= 0) return PGAN_EINVAL;
+    rows_sum_kernel<<<(J + 31) / 32, 256, 0, st>>>(x, J, coef, dw, J, 0, N, 0, 0, 0);
     return pgan_launch_status();
 }
 

@@ -36,16 +36,6 @@ __global__ void head_seed_kernel(const float* __restrict__ w, const float* __res
     reinterpret_cast<f32x4*>(u4)[i] = ww * c;
 }
 
-// dw[j] = sum_n coef[n] x[n][j]
-__global__ void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ coef, float* __restrict__ dw,
-                                  int N, int J) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(coef[n], x[(int64_t)n * J + j], s);
-    dw[j] = s;
-}
-
 __global__ void interpolate_kernel(const float* __restrict__ t, const float* __restrict__ real,
                                    const float* __restrict__ fake, float* __restrict__ out, int B, int M) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,12 +242,6 @@ int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float*
 int pgan_head_seed(const float* w, const float* coef, float* u4, int N, int K, hipStream_t st) {
     if (N <= 0 || K % 4) return PGAN_EINVAL;
     head_seed_kernel<<<grid_for((int64_t)N * K / 4, 256), 256, 0, st>>>(w, coef, u4, N, K);
-    return pgan_launch_status();
-}
-
-int pgan_head_wgrad(const float* x, const float* coef, float* dw, int N, int J, hipStream_t st) {
-    if (N <= 0 || J <= 0) return PGAN_EINVAL;
-    head_wgrad_kernel<<<grid_for(J, 256), 256, 0, st>>>(x, coef, dw, N, J);
     return pgan_launch_status();
 }
 

@@ -50,19 +50,19 @@ __device__ __forceinline__ void gn_stats(const float* a, int M, double* sh, floa
     r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
 }
 
-__global__ __launch_bounds__(256) void d1d_fwd_kernel(const float* __restrict__ xp, D1Params P, float* __restrict__ a1s,
+__global__ __launch_bounds__(1024) void d1d_fwd_kernel(const float* __restrict__ xp, D1Params P, float* __restrict__ a1s,
                                                       float* __restrict__ a2s, float* __restrict__ a3s,
                                                       float* __restrict__ feat) {
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], a3[D1_C3 * D1_L3];
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < D1_L0; i += 256) x0[i] = xp[(int64_t)n * D1_L0 + i];
+    for (int i = tid; i < D1_L0; i += blockDim.x) x0[i] = xp[(int64_t)n * D1_L0 + i];
     __syncthreads();
     float mu, r;
     conv1d_fwd<D1_C0, D1_C1, D1_L1>(x0, P.cw[0], P.cb[0], a1);
     __syncthreads();
     gn_stats(a1, D1_C1 * D1_L1, sh, mu, r);
-    for (int i = tid; i < D1_C1 * D1_L1; i += 256) {
+    for (int i = tid; i < D1_C1 * D1_L1; i += blockDim.x) {
         const int c = i / D1_L1;
         const float v = a1[i];
         a1s[(int64_t)n * D1_C1 * D1_L1 + i] = v;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void d1d_fwd_kernel(const float* __restrict__ 
     conv1d_fwd<D1_C1, D1_C2, D1_L2>(a1, P.cw[1], P.cb[1], a2);
     __syncthreads();
     gn_stats(a2, D1_C2 * D1_L2, sh, mu, r);
-    for (int i = tid; i < D1_C2 * D1_L2; i += 256) {
+    for (int i = tid; i < D1_C2 * D1_L2; i += blockDim.x) {
         const int c = i / D1_L2;
         const float v = a2[i];
         a2s[(int64_t)n * D1_C2 * D1_L2 + i] = v;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void d1d_fwd_kernel(const float* __restrict__ 
     conv1d_fwd<D1_C2, D1_C3, D1_L3>(a2, P.cw[2], P.cb[2], a3);
     __syncthreads();
     gn_stats(a3, D1_C3 * D1_L3, sh, mu, r);
-    for (int i = tid; i < D1_C3 * D1_L3; i += 256) {
+    for (int i = tid; i < D1_C3 * D1_L3; i += blockDim.x) {
         const int c = i / D1_L3;
         const float v = a3[i];
         a3s[(int64_t)n * D1_C3 * D1_L3 + i] = v;
@@ -167,21 +167,21 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
     }
 }
 
-__global__ __launch_bounds__(256) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
+__global__ __launch_bounds__(512) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
                                                       const float* __restrict__ a1s, const float* __restrict__ a2s,
                                                       const float* __restrict__ a3s, const float* __restrict__ coef,
                                                       const float* __restrict__ w_tail, float* __restrict__ part,
                                                       int part_ld, D1Offsets off, float* __restrict__ dxp) {
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], h1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], h2[D1_C2 * D1_L2],
         a3[D1_C3 * D1_L3], g3[D1_C3 * D1_L3], g2[D1_C2 * D1_L2], g1[D1_C1 * D1_L1], g0[D1_L0];
     const int n = blockIdx.x, tid = threadIdx.x;
     float* prow = part ? part + (int64_t)n * part_ld : nullptr;
-    for (int i = tid; i < D1_L0; i += 256) x0[i] = xp[(int64_t)n * D1_L0 + i];
-    for (int i = tid; i < D1_C1 * D1_L1; i += 256) a1[i] = a1s[(int64_t)n * D1_C1 * D1_L1 + i];
-    for (int i = tid; i < D1_C2 * D1_L2; i += 256) a2[i] = a2s[(int64_t)n * D1_C2 * D1_L2 + i];
+    for (int i = tid; i < D1_L0; i += blockDim.x) x0[i] = xp[(int64_t)n * D1_L0 + i];
+    for (int i = tid; i < D1_C1 * D1_L1; i += blockDim.x) a1[i] = a1s[(int64_t)n * D1_C1 * D1_L1 + i];
+    for (int i = tid; i < D1_C2 * D1_L2; i += blockDim.x) a2[i] = a2s[(int64_t)n * D1_C2 * D1_L2 + i];
     const float cf = coef[n];
-    for (int i = tid; i < D1_C3 * D1_L3; i += 256) {
+    for (int i = tid; i < D1_C3 * D1_L3; i += blockDim.x) {
         a3[i] = a3s[(int64_t)n * D1_C3 * D1_L3 + i];
         g3[i] = cf * w_tail[i];
     }
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(256) void d1d_bwd_kernel(const float* __restrict__ 
     gn_stats(a1, D1_C1 * D1_L1, sh, mu1, r1);
     gn_stats(a2, D1_C2 * D1_L2, sh, mu2, r2);
     gn_stats(a3, D1_C3 * D1_L3, sh, mu3, r3);
-    for (int i = tid; i < D1_C1 * D1_L1; i += 256) {
+    for (int i = tid; i < D1_C1 * D1_L1; i += blockDim.x) {
         const int c = i / D1_L1;
         h1[i] = lrelu(P.gw[0][c] * ((a1[i] - mu1) * r1) + P.gb[0][c]);
     }
-    for (int i = tid; i < D1_C2 * D1_L2; i += 256) {
+    for (int i = tid; i < D1_C2 * D1_L2; i += blockDim.x) {
         const int c = i / D1_L2;
         h2[i] = lrelu(P.gw[1][c] * ((a2[i] - mu2) * r2) + P.gb[1][c]);
     }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void d1d_bwd_kernel(const float* __restrict__ 
                                     dxp ? g0 : nullptr);
     __syncthreads();
     if (dxp)
-        for (int i = tid; i < D1_L0; i += 256) dxp[(int64_t)n * D1_L0 + i] = g0[i];
+        for (int i = tid; i < D1_L0; i += blockDim.x) dxp[(int64_t)n * D1_L0 + i] = g0[i];
 }
 
 // ---------------- generator 1-D tower: ConvTranspose1d(k4, s2, p1) pair, weight w[Cs][Cl][4] ----------------
@@ -338,7 +338,7 @@ extern "C" {
 int pgan_d1d_fwd(const float* xp, const float* const* params, float* a1, float* a2, float* a3, float* feat, int N,
                  hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
-    d1d_fwd_kernel<<<N, 256, 0, st>>>(xp, make_params(params), a1, a2, a3, feat);
+    d1d_fwd_kernel<<<N, 1024, 0, st>>>(xp, make_params(params), a1, a2, a3, feat);
     return pgan_launch_status();
 }
 
@@ -350,7 +350,7 @@ int pgan_d1d_bwd(const float* xp, const float* const* params, const float* a1, c
     if (N <= 0 || (part && !offs)) return PGAN_EINVAL;
     D1Offsets o;
     for (int i = 0; i < 12; ++i) o.o[i] = offs ? offs[i] : 0;
-    d1d_bwd_kernel<<<N, 256, 0, st>>>(xp, make_params(params), a1, a2, a3, coef, w_tail, part, part_ld, o, dxp);
+    d1d_bwd_kernel<<<N, 512, 0, st>>>(xp, make_params(params), a1, a2, a3, coef, w_tail, part, part_ld, o, dxp);
     return pgan_launch_status();
 }
 

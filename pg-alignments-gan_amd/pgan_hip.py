@@ -63,13 +63,20 @@ _SIGS = {
     "pgan_ct1d_wgrad": [P, P, P, I, I, I, I, P],
     "pgan_gemm": [P, P, P, I, I, I, I, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats"])
+EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = c_int
 _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
+_lib.pgan_set_option.argtypes = [ctypes.c_char_p, c_int]
+_lib.pgan_set_option.restype = c_int
+
+
+def set_option(name: str, value: int) -> None:
+    """Kernel-variant override for tuning runs (0 = size-based choice)."""
+    _check(_lib.pgan_set_option(name.encode(), int(value)), f"pgan_set_option({name}, {value})")
 
 
 def _ptr(t: Optional[torch.Tensor]):

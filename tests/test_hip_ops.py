@@ -49,25 +49,37 @@ LAYERS = [(128, 64, 16), (256, 128, 8), (512, 256, 4)]   # (Cs, Cl, hs)
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
 @pytest.mark.parametrize("N", [5, 8])
-def test_conv_down(hip, Cs, Cl, hs, N):
+@pytest.mark.parametrize("kg", [0, 1, 2, 4])
+def test_conv_down(hip, Cs, Cl, hs, N, kg):
+    from pgan_hip import set_option
     rng = np.random.default_rng(1)
     x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
     want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
     REF.conv_down(*d64(x, w), want)
     got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
-    hip.conv_down(*gpu(x, w), got)
+    set_option("down_kg", kg)
+    try:
+        hip.conv_down(*gpu(x, w), got)
+    finally:
+        set_option("down_kg", 0)
     close("conv_down", got, want)
 
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
 @pytest.mark.parametrize("N", [5, 8])
-def test_conv_up(hip, Cs, Cl, hs, N):
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_conv_up(hip, Cs, Cl, hs, N, mode):
+    from pgan_hip import set_option
     rng = np.random.default_rng(2)
     y, w = rnd(rng, N, Cs, hs, hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
     want = torch.zeros(N, Cl, 2 * hs, 2 * hs, dtype=torch.float64)
     REF.conv_up(*d64(y, w), want)
     got = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
-    hip.conv_up(*gpu(y, w), got)
+    set_option("up_mode", mode)
+    try:
+        hip.conv_up(*gpu(y, w), got)
+    finally:
+        set_option("up_mode", 0)
     close("conv_up", got, want)
 
 
