@@ -129,12 +129,14 @@ __global__ __launch_bounds__(256 * KG) void conv_down_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    const int nk = Cl / (CLC * KG);
-    gload(grp * CLC);
+    // gridDim.y > 1: the channel range is also split across blocks, which then add into a zeroed Y
+    const int nk = Cl / (CLC * KG * (int)gridDim.y);
+    const int kc0 = blockIdx.y * nk;
+    gload((kc0 * KG + grp) * CLC);
     for (int kc = 0; kc < nk; ++kc) {
         lstore();
         __syncthreads();
-        if (kc + 1 < nk) gload(((kc + 1) * KG + grp) * CLC);
+        if (kc + 1 < nk) gload(((kc0 + kc + 1) * KG + grp) * CLC);
 #pragma unroll
         for (int c = 0; c < CLC; ++c)
 #pragma unroll
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(256 * KG) void conv_down_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Y[(((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow] = acc[tm][tn][r];
+                float* dst = Y + (((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow;
+                if (gridDim.y > 1) atomicAdd(dst, acc[tm][tn][r]);
+                else *dst = acc[tm][tn][r];
             }
     }
 }
@@ -797,6 +801,7 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
 constexpr int FILL_WAVES = 2048;
 // tuning overrides (0 = choose from the launch size): see pgan_set_option
 int g_down_kg = 0;     // 1, 2, 4: K groups of the DOWN kernel
+int g_down_ks = 0;     // 1, 2: K split across blocks of the DOWN kernel (2 partial sums added atomically)
 int g_up_mode = 0;     // 1: all-phase 64x64 tiles; 2: phase-split, no K split; 3: phase-split, 2 K groups
 
 template <int HS>
@@ -804,11 +809,17 @@ int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl,
     constexpr int BM = 64, BN = 64;
     if (Cs % BM || Cl % 16) return PGAN_EINVAL;
     const int grid = (Cs / BM) * PixTile<HS, BN>::ntiles(N);
-    const int waves = grid * 4;
+    // Fewer than ~2 blocks per CU: split K over two blocks as well (two partial sums added onto a
+    // zeroed output: the sum of two terms does not depend on their order).
+    const int ks = g_down_ks ? g_down_ks : ((grid < 512 && Cl >= 128) ? 2 : 1);
+    const int waves = grid * 4 * ks;
     const int kg = g_down_kg ? g_down_kg : (waves >= FILL_WAVES ? 1 : (waves * 2 >= FILL_WAVES ? 2 : 4));
-    if (kg == 1) conv_down_kernel<HS, BM, BN, 8, 1><<<grid, 256, 0, st>>>(X, W, Y, N, Cs, Cl);
-    else if (kg == 2) conv_down_kernel<HS, BM, BN, 4, 2><<<grid, 512, 0, st>>>(X, W, Y, N, Cs, Cl);
-    else conv_down_kernel<HS, BM, BN, 4, 4><<<grid, 1024, 0, st>>>(X, W, Y, N, Cs, Cl);
+    if (Cl % (8 * ks) || Cl % (4 * kg * ks)) return PGAN_EINVAL;
+    if (ks > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
+    const dim3 g(grid, ks);
+    if (kg == 1) conv_down_kernel<HS, BM, BN, 8, 1><<<g, 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+    else if (kg == 2) conv_down_kernel<HS, BM, BN, 4, 2><<<g, 512, 0, st>>>(X, W, Y, N, Cs, Cl);
+    else conv_down_kernel<HS, BM, BN, 4, 4><<<g, 1024, 0, st>>>(X, W, Y, N, Cs, Cl);
     return pgan_launch_status();
 }
 template <int HS>
@@ -817,8 +828,11 @@ int launch_up(const float* Y, const float* W, float* X, int N, int Cs, int Cl, h
     if (Cl % BM || Cs % 32) return PGAN_EINVAL;
     const int grid = (Cl / BM) * PixTile<HS, BN>::ntiles(N);
     const int grid_ps = (Cl / 32) * PixTile<HS, 32>::ntiles(N);
+    // all-phase 64x64 tiles run 2 blocks per CU: use them when they fill whole rounds of 512 blocks
+    // (always at hs = 16, where the phase-split form's stride-2 stores cost more than the idle CUs)
     int mode = g_up_mode;
-    if (!mode) mode = (grid * 4 >= 2 * FILL_WAVES) ? 1 : (grid_ps * 4 >= FILL_WAVES ? 2 : 3);
+    if (!mode) mode = (HS == 16 || grid * 10 >= ((grid + 511) / 512) * 512 * 9) ? 1 : 3;
+    (void)FILL_WAVES;
     if (mode == 1) conv_up_kernel<HS, BM, BN, CSC><<<grid, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
     else if (mode == 2) conv_up_ps_kernel<HS, 16, 1><<<grid_ps, 256, 0, st>>>(Y, W, X, N, Cs, Cl);
     else conv_up_ps_kernel<HS, 8, 2><<<grid_ps, 512, 0, st>>>(Y, W, X, N, Cs, Cl);
@@ -862,6 +876,7 @@ int pgan_set_option(const char* name, int value) {
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, a) && (value == 0 || value == 1 || value == 2 || value == 4)) { g_down_kg = value; return PGAN_OK; }
     if (eq(name, b) && value >= 0 && value <= 3) { g_up_mode = value; return PGAN_OK; }
+    if (eq(name, "down_ks") && value >= 0 && value <= 2) { g_down_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 

@@ -125,6 +125,48 @@ class FlatStore:
             v.copy_(params[k].to(v.device, torch.float32))
 
 
+class SideStream:
+    """Second HIP stream for the small position-vector towers: they are latency-bound chains of tiny
+    kernels that depend only on parameters and their own inputs, so they run beside the 2-D towers'
+    large convolution kernels (also under graph capture, where fork/join become graph edges).
+    On the CPU backend every method is a no-op."""
+
+    def __init__(self, device):
+        self.enabled = torch.device(device).type == "cuda"
+        if self.enabled:
+            self.stream = torch.cuda.Stream(device=device)
+            self.mark = torch.cuda.Event()
+
+    def fork(self):
+        if self.enabled:
+            self.stream.wait_stream(torch.cuda.current_stream())
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def set_mark(self):
+        """Called on the side stream: remember this point."""
+        if self.enabled:
+            self.mark.record(self.stream)
+
+    def wait_mark(self):
+        """Called on the main stream: wait for the side stream's mark."""
+        if self.enabled:
+            torch.cuda.current_stream().wait_event(self.mark)
+
+    def __enter__(self):
+        if self.enabled:
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.enabled:
+            self._ctx.__exit__(*a)
+        return False
+
+
 class Engine:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  latent: int = LATENT, lr_d: float = 5e-5, lr_g: float = 5e-5,
@@ -150,6 +192,7 @@ class Engine:
             if k.endswith("running_var"):
                 v.fill_(1.0)
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
+        self.side = SideStream(device)
 
         NT = self.NT
         # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
@@ -241,10 +284,17 @@ class Engine:
     def gen_forward(self, z: torch.Tensor, out_s: torch.Tensor, out_p: torch.Tensor) -> None:
         """(sites, positions) = G(z), BatchNorm in training mode (layers.py:143-147).  Activations
         stay in the generator workspace for a following gen_backward."""
-        o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         if z.data_ptr() != self.Z.data_ptr():
             self.Z.copy_(z.reshape(self.B, self.latent))
         self.g_batches_tracked += 1
+        self.side.fork()
+        with self.side:
+            self._gen_forward_1d(out_p)
+        self._gen_forward_2d(out_s)
+        self.side.join()
+
+    def _gen_forward_2d(self, out_s: torch.Tensor) -> None:
+        o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         o.gemm_nn(self.Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), self.gA[1].view(self.B, -1))
         for i in range(1, 5):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
@@ -255,6 +305,9 @@ class Engine:
                 o.conv_up(self.gH[i], w, self.gA[i + 1])
             else:
                 o.conv_up(self.gH[i], w, out_s, self.act_id)
+
+    def _gen_forward_1d(self, out_p: torch.Tensor) -> None:
+        o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         o.gemm_nn(self.Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), self.hA[1].view(self.B, -1))
         for i in range(1, 5):
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
@@ -269,6 +322,13 @@ class Engine:
     def gen_backward(self, xs, xp, dxs, dxp) -> None:
         """Gradients of every generator parameter given d loss/d sites and d loss/d positions of the
         batch produced by the preceding gen_forward (into self.G.g, overwritten)."""
+        self.side.fork()
+        with self.side:
+            self._gen_backward_1d(xp, dxp)
+        self._gen_backward_2d(xs, dxs)
+        self.side.join()
+
+    def _gen_backward_2d(self, xs, dxs) -> None:
         o, G, dG = self.ops, self.G.p, self.G.g
         o.act_bwd(dxs, xs, self.gdX, self.act_id)
         up = self.gdX
@@ -281,6 +341,9 @@ class Engine:
                      dG[n + ".weight"], dG[n + ".bias"])
             up = self.gdA[i]
         o.gemm_tn(self.Z, self.gdA[1].view(self.B, -1), dG["twod_conv_layers.0.weight"].view(self.latent, -1))
+
+    def _gen_backward_1d(self, xp, dxp) -> None:
+        o, G, dG = self.ops, self.G.p, self.G.g
         o.act_bwd(dxp, xp, self.hdX, self.act_id)
         up = self.hdX
         for i in range(4, 0, -1):
@@ -349,13 +412,26 @@ class Engine:
         z in Z, t in tbuf."""
         o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
         Dp, Dg = self.D.p, self.D.g
-        self.gen_forward(self.Z, self.X0[B:2 * B], self.P0[B:2 * B])
+        cw, cb, gw, gb = self._d1d_params(Dp)
+        dcw, dcb, dgw, dgb = self._d1d_params(Dg)
+        self.g_batches_tracked += 1
+        # side stream: the whole position-vector chain (generator 1-D tower, discriminator 1-D tower
+        # forward and backward); it depends on the main stream only through what is ready here
+        self.side.fork()
+        with self.side:
+            self._gen_forward_1d(self.P0[B:2 * B])
+            o.d1d_fwd(self.P0, cw, cb, gw, gb, self.d1A, self.F1)
+            self.side.set_mark()
+            o.d1d_bwd(self.P0, cw, cb, gw, gb, self.d1A, self.coef_w, Dp["out.weight"].view(-1)[FEAT2:],
+                      dcw, dcb, dgw, dgb, None)
+            o.head_wgrad(self.F1, self.coef_w, Dg["out.weight"].view(-1)[FEAT2:])
+            o.head_wgrad(self.ones2B, self.coef_w, Dg["out.bias"])
+        self._gen_forward_2d(self.X0[B:2 * B])
         if self.loss == "gp":
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
         # primal forward
         self._d_forward2d(0, NS)
-        cw, cb, gw, gb = self._d1d_params(Dp)
-        o.d1d_fwd(self.P0, cw, cb, gw, gb, self.d1A, self.F1)
+        self.side.wait_mark()
         o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
         # first-order backward (+ input gradient of the penalised samples)
         self.coef_cur = self.coef
@@ -397,11 +473,7 @@ class Engine:
             o.rows_reduce(self.dPG[k], Dg[gname + ".weight"], *r)
             o.rows_reduce(self.dPB[k], Dg[gname + ".bias"], *r)
         o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
-        o.head_wgrad(self.F1, self.coef_w, Dg["out.weight"].view(-1)[FEAT2:])
-        o.head_wgrad(self.ones2B, self.coef_w, Dg["out.bias"])
-        dcw, dcb, dgw, dgb = self._d1d_params(Dg)
-        o.d1d_bwd(self.P0, cw, cb, gw, gb, self.d1A, self.coef_w, Dp["out.weight"].view(-1)[FEAT2:],
-                  dcw, dcb, dgw, dgb, None)
+        self.side.join()
 
     def critic_step(self, real_s, real_p, z, t=None) -> None:
         self.critic_grads(real_s, real_p, z, t)
@@ -420,19 +492,28 @@ class Engine:
         """generator_grads with z already in self.Z."""
         o, B = self.ops, self.B
         Dp = self.D.p
-        self.gen_forward(self.Z, self.gXs, self.gXp)
-        self.X0[:B].copy_(self.gXs)
-        self.P0[:B].copy_(self.gXp)
-        self._d_forward2d(0, B)
         cw, cb, gw, gb = self._d1d_params(Dp)
-        o.d1d_fwd(self.P0[:B], cw, cb, gw, gb, [a[:B] for a in self.d1A], self.F1[:B])
+        a1 = [a[:B] for a in self.d1A]
+        self.g_batches_tracked += 1
+        self.side.fork()
+        with self.side:   # positions: G 1-D forward, D 1-D forward, D 1-D input gradient, G 1-D backward
+            self._gen_forward_1d(self.gXp)
+            self.P0[:B].copy_(self.gXp)
+            o.d1d_fwd(self.P0[:B], cw, cb, gw, gb, a1, self.F1[:B])
+            self.side.set_mark()
+            o.d1d_bwd(self.P0[:B], cw, cb, gw, gb, a1, self.coef_gen, Dp["out.weight"].view(-1)[FEAT2:],
+                      None, None, None, None, self.dP0)
+            self._gen_backward_1d(self.gXp, self.dP0)
+        self._gen_forward_2d(self.gXs)
+        self.X0[:B].copy_(self.gXs)
+        self._d_forward2d(0, B)
+        self.side.wait_mark()
         o.head_fwd(self.dH[4][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])
         o.neg_mean(self.score[:B], self.gloss)
         self.coef_cur = self.coef_gen
         self._d_backward1(0, B, 0, B, self.G0[:B])
-        o.d1d_bwd(self.P0[:B], cw, cb, gw, gb, [a[:B] for a in self.d1A], self.coef_gen,
-                  Dp["out.weight"].view(-1)[FEAT2:], None, None, None, None, self.dP0)
-        self.gen_backward(self.gXs, self.gXp, self.G0[:B], self.dP0)
+        self._gen_backward_2d(self.gXs, self.G0[:B])
+        self.side.join()
 
     def generator_step(self, z) -> None:
         self.generator_grads(z)

@@ -49,7 +49,7 @@ LAYERS = [(128, 64, 16), (256, 128, 8), (512, 256, 4)]   # (Cs, Cl, hs)
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
 @pytest.mark.parametrize("N", [5, 8])
-@pytest.mark.parametrize("kg", [0, 1, 2, 4])
+@pytest.mark.parametrize("kg", [0, 1, 2, 4, 12, 14])
 def test_conv_down(hip, Cs, Cl, hs, N, kg):
     from pgan_hip import set_option
     rng = np.random.default_rng(1)
@@ -57,11 +57,13 @@ def test_conv_down(hip, Cs, Cl, hs, N, kg):
     want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
     REF.conv_down(*d64(x, w), want)
     got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
-    set_option("down_kg", kg)
+    set_option("down_kg", kg % 10)           # 12 / 14: K also split over two blocks
+    set_option("down_ks", 2 if kg >= 10 else (1 if kg else 0))
     try:
         hip.conv_down(*gpu(x, w), got)
     finally:
         set_option("down_kg", 0)
+        set_option("down_ks", 0)
     close("conv_down", got, want)
 
 

@@ -1,0 +1,39 @@
+"""Micro-benchmark of the conv kernel variants (tuning aid; run on the GPU box)."""
+import sys, os, itertools
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pg-alignments-gan_amd"))
+import torch
+from pgan_hip import HipOps, set_option
+dev = torch.device("cuda:0")
+ops = HipOps(dev)
+LAYERS = [(128, 64, 16), (256, 128, 8), (512, 256, 4)]
+def timeit(fn, reps=30):
+    for _ in range(5): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+for N in (64, 192, 256, 320):
+    for Cs, Cl, hs in LAYERS:
+        fl = 2.0 * N * Cs * Cl * 16 * hs * hs
+        y = torch.randn(N, Cs, hs, hs, device=dev); x = torch.randn(N, Cl, 2*hs, 2*hs, device=dev)
+        w = torch.randn(Cs, Cl, 4, 4, device=dev) * 0.05; dw = torch.zeros_like(w)
+        if which in ("all", "up"):
+            for mode in (1, 2, 3):
+                set_option("up_mode", mode)
+                us = timeit(lambda: ops.conv_up(y, w, x))
+                print(f"up   N={N:3d} hs={hs:2d} mode={mode}: {us:8.1f} us {fl/us/1e6:7.1f} TF")
+            set_option("up_mode", 0)
+        if which in ("all", "down"):
+            for ks in (1, 2):
+                for kg in (1, 2, 4):
+                    set_option("down_kg", kg); set_option("down_ks", ks)
+                    us = timeit(lambda: ops.conv_down(x, w, y))
+                    print(f"down N={N:3d} hs={hs:2d} ks={ks} kg={kg}:   {us:8.1f} us {fl/us/1e6:7.1f} TF")
+            set_option("down_kg", 0); set_option("down_ks", 0)
+            us = timeit(lambda: ops.conv_down(x, w, y))
+            print(f"down N={N:3d} hs={hs:2d} auto:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
+        if which in ("all", "wgrad"):
+            us = timeit(lambda: ops.conv_wgrad(y, x, dw))
+            print(f"wgrd N={N:3d} hs={hs:2d}:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
