@@ -170,7 +170,9 @@ class SideStream:
 class Engine:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  latent: int = LATENT, lr_d: float = 5e-5, lr_g: float = 5e-5,
-                 betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8):
+                 betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8,
+                 g_store: Optional["FlatStore"] = None, g_buffers: Optional["FlatStore"] = None,
+                 d_store: Optional["FlatStore"] = None):
         if loss not in ("gp", "div"):
             raise ValueError(f"loss must be 'gp' or 'div', got {loss!r}")
         if act not in ("sigmoid", "tanh"):
@@ -185,12 +187,16 @@ class Engine:
         self.NT = self.NS + self.NP                     # = 4B
         f = dict(dtype=torch.float32, device=device)
 
-        self.D = FlatStore(disc_param_shapes(), device)
-        self.G = FlatStore(gen_param_shapes(latent), device)
-        self.Gbuf = FlatStore(gen_buffer_shapes(latent), device, with_opt=False)
-        for k, v in self.Gbuf.p.items():
-            if k.endswith("running_var"):
-                v.fill_(1.0)
+        # parameter stores may be handed in (the nn.Module front-ends own theirs) or created here
+        self.D = d_store if d_store is not None else FlatStore(disc_param_shapes(), device)
+        self.G = g_store if g_store is not None else FlatStore(gen_param_shapes(latent), device)
+        if g_buffers is not None:
+            self.Gbuf = g_buffers
+        else:
+            self.Gbuf = FlatStore(gen_buffer_shapes(latent), device, with_opt=False)
+            for k, v in self.Gbuf.p.items():
+                if k.endswith("running_var"):
+                    v.fill_(1.0)
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
         self.side = SideStream(device)
 
@@ -248,22 +254,27 @@ class Engine:
         self.hdX = torch.zeros(B, 1, 64, **f)
 
     # ------------------------------------------------------------------------------------------
-    def _init_coefs(self):
+    def _init_coefs(self, wasserstein: bool = True):
+        """Per-slot seeds.  wasserstein=False drops the mean(D(fake)) - mean(D(real)) term so that
+        critic_grads* produce the gradient of the penalty alone."""
         B, NS = self.B, self.NS
+        ws = 1.0 / B if wasserstein else 0.0
         c = torch.zeros(self.NT)
         ch = torch.zeros(self.NT)
         if self.loss == "gp":
-            c[:B], c[B:2 * B], c[2 * B:3 * B] = -1.0 / B, 1.0 / B, 1.0
-            ch[:B], ch[B:2 * B], ch[3 * B:] = -1.0 / B, 1.0 / B, 1.0
+            c[:B], c[B:2 * B], c[2 * B:3 * B] = -ws, ws, 1.0
+            ch[:B], ch[B:2 * B], ch[3 * B:] = -ws, ws, 1.0
         else:
             c[:2 * B] = 1.0
-            ch[:B], ch[B:2 * B], ch[2 * B:] = -1.0 / B, 1.0 / B, 1.0
-            top = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)])
+            ch[:B], ch[B:2 * B], ch[2 * B:] = -ws, ws, 1.0
+            top = torch.cat([torch.full((B,), -ws), torch.full((B,), ws)])
             self.coef_top.copy_(top)
         self.coef.copy_(c)
         self.coef_head.copy_(ch)
-        w1 = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)])
-        self.coef_w = w1.to(self.dev)
+        w1 = torch.cat([torch.full((B,), -ws), torch.full((B,), ws)])
+        if not hasattr(self, "coef_w"):
+            self.coef_w = torch.zeros(2 * B, dtype=torch.float32, device=self.dev)
+        self.coef_w.copy_(w1)
 
     def dconv_w(self, k):
         return self.D.p[f"twod_conv_layers.{3 * (k - 1)}.weight"]
@@ -391,6 +402,30 @@ class Engine:
         o.d1d_fwd(self.P0[:n], cw, cb, gw, gb, [a[:n] for a in self.d1A], self.F1[:n])
         o.head_fwd(self.dH[4][:n], self.F1[:n], self.D.p["out.weight"], self.D.p["out.bias"], score)
 
+    def disc_backward(self, n: int, coef: torch.Tensor, dxs: Optional[torch.Tensor] = None,
+                      dxp: Optional[torch.Tensor] = None, want_params: bool = True) -> None:
+        """Plain backward of sum_i coef[i] * score[i] for the n samples of the preceding disc_forward:
+        parameter gradients into self.D.g (overwritten) and, when given, the input gradients."""
+        o, Dp, Dg = self.ops, self.D.p, self.D.g
+        cw, cb, gw, gb = self._d1d_params(Dp)
+        self.coef_cur = coef
+        self._d_backward1(0, n, 0, n, dxs)
+        a1 = [a[:n] for a in self.d1A]
+        wt = Dp["out.weight"].view(-1)[FEAT2:]
+        if want_params:
+            for k in range(1, 5):
+                o.conv_wgrad(self.dJ[k][:n], self.dH[k - 1][:n], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
+                gname = f"twod_conv_layers.{3 * (k - 1) + 1}"
+                o.rows_reduce(self.dPG[k], Dg[gname + ".weight"], 0, n, 0, 0)
+                o.rows_reduce(self.dPB[k], Dg[gname + ".bias"], 0, n, 0, 0)
+            o.head_wgrad(self.dH[4][:n], coef, Dg["out.weight"].view(-1)[:FEAT2])
+            o.head_wgrad(self.F1[:n], coef, Dg["out.weight"].view(-1)[FEAT2:])
+            o.head_wgrad(self.ones2B[:n], coef, Dg["out.bias"])
+            dcw, dcb, dgw, dgb = self._d1d_params(Dg)
+            o.d1d_bwd(self.P0[:n], cw, cb, gw, gb, a1, coef, wt, dcw, dcb, dgw, dgb, dxp)
+        elif dxp is not None:
+            o.d1d_bwd(self.P0[:n], cw, cb, gw, gb, a1, coef, wt, None, None, None, None, dxp)
+
     # ------------------------------------------------------------------------------------------
     # critic step
     # ------------------------------------------------------------------------------------------
@@ -407,26 +442,40 @@ class Engine:
             self.tbuf.copy_(t.reshape(B))
         self.critic_grads_resident()
 
-    def critic_grads_resident(self) -> None:
+    def critic_grads_given_fake(self, real_s, real_p, fake_s, fake_p, t=None) -> None:
+        """critic_grads for a fake batch that was generated elsewhere (the generator is not run)."""
+        B = self.B
+        self.X0[:B].copy_(real_s)
+        self.P0[:B].copy_(real_p)
+        self.X0[B:2 * B].copy_(fake_s)
+        self.P0[B:2 * B].copy_(fake_p)
+        if self.loss == "gp":
+            self.tbuf.copy_(t.reshape(B))
+        self.critic_grads_resident(run_generator=False)
+
+    def critic_grads_resident(self, run_generator: bool = True) -> None:
         """critic_grads on inputs already placed in the workspace: real batch in X0[:B] / P0[:B],
-        z in Z, t in tbuf."""
+        z in Z, t in tbuf (and, with run_generator=False, the fake batch in X0[B:2B] / P0[B:2B])."""
         o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
         Dp, Dg = self.D.p, self.D.g
         cw, cb, gw, gb = self._d1d_params(Dp)
         dcw, dcb, dgw, dgb = self._d1d_params(Dg)
-        self.g_batches_tracked += 1
+        if run_generator:
+            self.g_batches_tracked += 1
         # side stream: the whole position-vector chain (generator 1-D tower, discriminator 1-D tower
         # forward and backward); it depends on the main stream only through what is ready here
         self.side.fork()
         with self.side:
-            self._gen_forward_1d(self.P0[B:2 * B])
+            if run_generator:
+                self._gen_forward_1d(self.P0[B:2 * B])
             o.d1d_fwd(self.P0, cw, cb, gw, gb, self.d1A, self.F1)
             self.side.set_mark()
             o.d1d_bwd(self.P0, cw, cb, gw, gb, self.d1A, self.coef_w, Dp["out.weight"].view(-1)[FEAT2:],
                       dcw, dcb, dgw, dgb, None)
             o.head_wgrad(self.F1, self.coef_w, Dg["out.weight"].view(-1)[FEAT2:])
             o.head_wgrad(self.ones2B, self.coef_w, Dg["out.bias"])
-        self._gen_forward_2d(self.X0[B:2 * B])
+        if run_generator:
+            self._gen_forward_2d(self.X0[B:2 * B])
         if self.loss == "gp":
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
         # primal forward

@@ -34,6 +34,7 @@ class FusedTrainer:
         self.pool_s: Optional[torch.Tensor] = None
         self.pool_p: Optional[torch.Tensor] = None
         self.graph = None
+        self.use_graph = False       # step(): capture on the first call, replay afterwards
         self.iterations = 0
 
     def set_pool(self, sites: torch.Tensor, pos: torch.Tensor, normalize: bool = False) -> None:
@@ -46,6 +47,70 @@ class FusedTrainer:
             self.ops.affine(self.pool_s, 2.0, -1.0, self.pool_s)
             self.ops.affine(self.pool_p, 2.0, -1.0, self.pool_p)
         self.cursor.zero_()
+
+    def shuffle_pool(self, rows: bool = False) -> None:
+        """Start of an epoch: new random order of the pool (the loader's on_epoch_end shuffle,
+        src/train_wgan_v2.py:239-242) and, with rows=True, an independent permutation of the 64
+        individuals of every alignment (np.random.shuffle(s), :257-258).  Device-side, outside
+        the captured step."""
+        n = self.pool_s.shape[0]
+        perm = torch.randperm(n, device=self.dev)
+        self.pool_s.copy_(self.pool_s[perm])
+        self.pool_p.copy_(self.pool_p[perm])
+        if rows:
+            order = torch.rand(n, 64, device=self.dev).argsort(dim=1)
+            idx = order.view(n, 1, 64, 1).expand(n, 1, 64, 64)
+            self.pool_s.copy_(torch.gather(self.pool_s, 2, idx))
+        self.cursor.zero_()
+
+    def enable_fake_buffer(self, size: int) -> None:
+        """Replay buffer of generated alignments (FakeBuffer, src/train_wgan_v2.py:98-117): every
+        critic step adds its fresh fakes to a bounded FIFO and trains on a batch drawn from it without
+        replacement.  Runs eagerly (sampling uses torch's device RNG)."""
+        B = self.eng.B
+        assert size >= B
+        self.buf_s = torch.zeros(size, 1, 64, 64, device=self.dev)
+        self.buf_p = torch.zeros(size, 1, 64, device=self.dev)
+        self.buf_count, self.buf_head = 0, 0
+        self.tmp_s = torch.zeros(B, 1, 64, 64, device=self.dev)
+        self.tmp_p = torch.zeros(B, 1, 64, device=self.dev)
+
+    def _critic_buffered(self) -> None:
+        e, o = self.eng, self.ops
+        B, size = e.B, self.buf_s.shape[0]
+        o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
+        o.philox(e.Z, self.rng_z, True)
+        if e.loss == "gp":
+            o.philox(e.tbuf, self.rng_t, False)
+        e.gen_forward(e.Z, self.tmp_s, self.tmp_p)
+        pos = (self.buf_head + torch.arange(B, device=self.dev)) % size
+        self.buf_s[pos] = self.tmp_s
+        self.buf_p[pos] = self.tmp_p
+        self.buf_head = (self.buf_head + B) % size
+        self.buf_count = min(size, self.buf_count + B)
+        pick = torch.randperm(self.buf_count, device=self.dev)[:B]
+        e.X0[B:2 * B].copy_(self.buf_s[pick])
+        e.P0[B:2 * B].copy_(self.buf_p[pick])
+        e.critic_grads_resident(run_generator=False)
+        self._allreduce(e.D.gflat)
+        e.adam_d()
+
+    def step(self) -> None:
+        """One iteration by the fastest available route."""
+        if getattr(self, "buf_s", None) is not None:
+            for _ in range(self.critic_iter):
+                self._critic_buffered()
+            self.ops.philox(self.eng.Z, self.rng_z, True)
+            self.eng.generator_grads_resident()
+            self._allreduce(self.eng.G.gflat)
+            self.eng.adam_g()
+            self.iterations += 1
+        elif self.graph is not None:
+            self.replay()
+        elif self.use_graph and self.world == 1:
+            self.capture()           # runs this iteration eagerly, then records the graph for the next ones
+        else:
+            self.iteration()
 
     def _allreduce(self, flat: torch.Tensor) -> None:
         if self.world > 1:
@@ -75,7 +140,8 @@ class FusedTrainer:
         self.iterations += 1
 
     def capture(self) -> None:
-        """Record one iteration into a hipGraph (single-GPU path; every launch is on static buffers)."""
+        """Run ONE iteration eagerly (it counts as a training iteration and warms every kernel on the
+        capture stream), then record the same launches into a hipGraph for replay()."""
         if self.world > 1:
             raise RuntimeError("graph capture is used on the single-GPU path only")
         torch.cuda.synchronize()

@@ -1,0 +1,326 @@
+"""DCWGAN-GP trainer for population-genetic alignments on MI355X: same command line, loaders and
+checkpoint names as the reference's /root/reference/src/train_wgan_v2.py, with the training
+loop (:509-640) replaced by the fused HIP step (pgan_trainer.FusedTrainer).
+
+    python3 train_wgan_v2.py --idir sims/ --odir out/ --use_cuda --loss gp --batch_size 64
+
+Differences from the reference, all deliberate:
+  * the selected alignments are read from disk ONCE, packed into a pool resident in HBM and the
+    critic_iter loop + generator step run as one hipGraph replay per iteration (no per-batch
+    np.loadtxt, no per-iteration host synchronisation: losses are read back only when logged);
+  * flags the reference parses but never reads are live: --gen (sigGen | tanGen | tanNorm),
+    --use_buffer/--buffer_n (replay buffer of generated alignments, :98-117), --permute /
+    --shuffle_inds (row shuffle of each real alignment), --label_smooth/--label_noise;
+  * an "epoch" is floor(num_in / batch / critic_iter) full iterations (the reference's extra
+    generator step on the exhausted loader, :531-532,:639-640, is not reproduced);
+  * --plot (matplotlib/scikit-allel evaluation figures) is not part of this package.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import logging
+import os
+import random
+import shutil
+import subprocess
+from collections import deque
+
+import numpy as np
+import torch
+
+MS_PATH = os.path.join(os.getcwd(), "msdir/ms")
+
+
+# ------------------------------------------------------------------------------------------------
+# loaders (host side; same constructor / get_batch contracts as the reference)
+# ------------------------------------------------------------------------------------------------
+class DataGeneratorDisk(object):
+    """src/train_wgan_v2.py:227-270.  `<n>_sites.csv` (64 lines of 64 comma-separated 0/1) and
+    `<n>_pos.csv` (64 floats, one per line) pairs; `num_in` of them are drawn with random.sample
+    (ValueError if the directory holds fewer), shuffled every epoch and served in batches."""
+
+    def __init__(self, idir, num_in=10000, batch_size=8):
+        pos = {os.path.basename(p)[:-len("_pos.csv")]: p for p in glob.glob(os.path.join(idir, "*_pos.csv"))}
+        sites = {os.path.basename(p)[:-len("_sites.csv")]: p for p in glob.glob(os.path.join(idir, "*_sites.csv"))}
+        keys = sorted(set(pos) & set(sites))
+        self.positions = [pos[k] for k in keys]
+        self.sites = [sites[k] for k in keys]
+        self.indices = random.sample(list(range(len(self.positions))), k=num_in)
+        self.length = len(self.indices) // batch_size
+        self.batch_size = batch_size
+        self.on_epoch_end()
+
+    def on_epoch_end(self):
+        random.shuffle(self.indices)
+        self.ix = 0
+
+    @staticmethod
+    def read_pair(site_file, pos_file):
+        s = np.loadtxt(site_file, delimiter=",", dtype=np.float32, ndmin=2)
+        p = np.loadtxt(pos_file, dtype=np.float32, ndmin=1)
+        return s, p
+
+    def get_batch(self, label_smooth=False, shuffle=False):
+        sel = self.indices[self.ix:self.ix + self.batch_size]
+        self.ix += self.batch_size
+        sites, pos = [], []
+        for u in sel:
+            s, p = self.read_pair(self.sites[u], self.positions[u])
+            if shuffle:
+                np.random.shuffle(s)
+            sites.append(s)
+            pos.append(p)
+        sites = np.array(sites, dtype=np.float32).reshape(len(sel), 64, 64) if sel else np.zeros((0, 64, 64), np.float32)
+        if label_smooth:
+            ey = np.random.uniform(0.0, 0.05, sites.shape)
+            sites = sites * (1 - ey) + 0.05 * ey
+        pos = np.array(pos, dtype=np.float32).reshape(len(sel), 64) if sel else np.zeros((0, 64), np.float32)
+        return torch.FloatTensor(sites[:, None]), torch.FloatTensor(pos[:, None])
+
+    def load_all(self):
+        """Every selected alignment, in index order: (num_in,1,64,64), (num_in,1,64) fp32."""
+        s = np.empty((len(self.indices), 1, 64, 64), np.float32)
+        p = np.empty((len(self.indices), 1, 64), np.float32)
+        for i, u in enumerate(self.indices):
+            s[i, 0], p[i, 0] = self.read_pair(self.sites[u], self.positions[u])
+        return torch.from_numpy(s), torch.from_numpy(p)
+
+
+class DataGenerator(object):
+    """src/train_wgan_v2.py:272-302: batches from in-memory tensors, sites smoothed towards 0.5."""
+
+    def __init__(self, sites_data, pos_data, batch_size=64):
+        self.sites_data, self.pos_data = sites_data, pos_data
+        self.length = self.sites_data.shape[0] // batch_size
+        self.batch_size = batch_size
+        self.on_epoch_end()
+
+    def __len__(self):
+        return self.length
+
+    def on_epoch_end(self):
+        self.indices = list(range(self.sites_data.shape[0]))
+        random.shuffle(self.indices)
+
+    def get_batch(self, sample=False):
+        take = self.indices[:self.batch_size]
+        xs = self.sites_data[take]
+        ey = torch.FloatTensor(np.random.uniform(0.0, 0.05, xs.shape))
+        xs = xs * (1 - ey) + 0.5 * ey
+        xp = self.pos_data[take]
+        if sample:
+            random.shuffle(self.indices)
+        else:
+            del self.indices[:self.batch_size]
+        return xs, xp
+
+
+def read_ms_data(ms_lines):
+    """Parse ms text output (src/train_wgan_v2.py:311-330): every replicate starts with '//', then
+    'segsites:', 'positions: ...' and one 0/1 string per individual.  As in the reference the last
+    replicate is dropped (callers ask ms for batch_size + 1).  Returns (R,1,64,S), (R,S,1)."""
+    starts = [i for i, ln in enumerate(ms_lines) if "//" in ln]
+    X, P = [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        chunk = ms_lines[a:b]
+        P.append(np.array([u for u in chunk[2].split(" ")[1:] if u.strip() != ""], dtype=np.float32))
+        rows = [ln.strip() for ln in chunk[3:] if ln.strip() != ""]
+        X.append(np.array([[int(c) for c in r] for r in rows], dtype=np.float32))
+    return np.expand_dims(np.array(X), 1), np.expand_dims(np.array(P), 2)
+
+
+class SimulatorGenerator(object):
+    """src/train_wgan_v2.py:332-351: simulate batch_size + 1 replicates with `ms` on the fly
+    (sim_class 0: constant size, 1: two demes of 32 with migration 0.01)."""
+
+    def __init__(self, batch_size=64, sim_class=1):
+        args = ["64", str(batch_size + 1), "-s", "64"]
+        if sim_class == 1:
+            args += ["-I", "2", "32", "32", "0.01"]
+        elif sim_class != 0:
+            raise ValueError("sim_class must be 0 or 1")
+        self.cmd = [MS_PATH] + args
+
+    def get_batch(self, label_smooth=True):
+        lines = subprocess.run(self.cmd, capture_output=True, text=True, check=True).stdout.split("\n")
+        sites, pos = read_ms_data(lines)
+        if label_smooth:   # formula as written in the reference (line 349)
+            ey = np.random.uniform(0.0, 0.1, sites.shape)
+            sites = sites * (1 - ey) + 0.5 * sites
+        return torch.FloatTensor(sites), torch.FloatTensor(pos).transpose(1, 2)
+
+
+class FakeBuffer(object):
+    """src/train_wgan_v2.py:98-117: bounded FIFO of generated alignments; sample() draws a batch
+    without replacement."""
+
+    def __init__(self, max_size=2560):
+        self.sites = deque(maxlen=max_size)
+        self.pos = deque(maxlen=max_size)
+        self.length = 0
+
+    def add(self, sites, pos):
+        self.sites.extend(list(sites))
+        self.pos.extend(list(pos))
+        self.length = len(self.sites)
+
+    def sample(self, batch_size=64):
+        ix = np.random.choice(range(self.length), batch_size, replace=False)
+        return (torch.stack([torch.as_tensor(self.sites[u]) for u in ix]).float(),
+                torch.stack([torch.as_tensor(self.pos[u]) for u in ix]).float())
+
+
+def switch_monomorphic(sites, positions, lower_bound, upper_bound):
+    """src/train_wgan_v2.py:129-160: per alignment, turn a random 0..n columns monomorphic (first
+    half all-ancestral, second half all-derived) and redraw their positions between the neighbours."""
+    for aln in range(sites.shape[0]):
+        n_mono = random.randint(lower_bound, upper_bound)
+        cols = np.random.choice(range(sites.shape[3]), n_mono, replace=False)
+        half = len(cols) // 2
+        sites[aln, :, :, cols[:half]] = 0.0
+        sites[aln, :, :, cols[half:]] = 1.0
+        last = positions.shape[2] - 1
+        for i in cols:
+            lo = 0.0 if i == 0 else float(positions[aln, 0, i - 1])
+            hi = 1.0 if i == last else float(positions[aln, 0, i + 1])
+            positions[aln, :, i] = float(np.random.uniform(lo, hi))
+    return sites, positions
+
+
+def sample_genotypes_bernoulli(sites_tensor, require_variation=True):
+    """src/train_wgan_v2.py:162-192: Bernoulli genotypes from the generator's probabilities; a column
+    that came out monomorphic is redrawn and one individual, picked in proportion to its probability
+    of carrying the missing allele, is set to it."""
+    out = torch.bernoulli(sites_tensor)
+    if not require_variation:
+        return out
+    mono = (out.amin(dim=2) == out.amax(dim=2))[:, 0]           # (B, S)
+    for aln, col in mono.nonzero().tolist():
+        have = float(out[aln, 0, 0, col])
+        probs = sites_tensor[aln, 0, :, col].detach().cpu().numpy().astype(np.float64)
+        if have == 1.0:
+            probs = 1 - probs
+        probs = probs + 1e-7
+        pick = np.random.choice(range(out.shape[2]), 1, p=probs / probs.sum())[0]
+        out[aln, :, :, col] = torch.bernoulli(sites_tensor[aln, :, :, col])
+        out[aln, :, pick, col] = 1 - have
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--latent_size", default="128", help="size of latent/noise vector")
+    p.add_argument("--idir", default="ms_sims/64ind_6sites_5.16e-04theta_10krep_pos/", help="input directory")
+    p.add_argument("--odir", default="output/", help="output directory")
+    p.add_argument("--plot", action="store_true", help="plot summaries in output")
+    p.add_argument("--gen", default="sigGen", help="generator type: sigGen tanGen tanNorm")
+    p.add_argument("--loss", default="gp", help="gp or div")
+    p.add_argument("--gen_lr", default="0.00005", help="generator learning rate")
+    p.add_argument("--disc_lr", default="0.00005", help="discriminator learning rate")
+    p.add_argument("--num_in", default="10000", help="number of input alignments")
+    p.add_argument("--use_cuda", action="store_true", help="run on the GPU (required)")
+    p.add_argument("--save_freq", default="0", help="save model every save_freq epochs (0: never)")
+    p.add_argument("--batch_size", default="64", help="batch size")
+    p.add_argument("--epochs", default="10000", help="total number of epochs")
+    p.add_argument("--critic_iter", default="5", help="critic updates per generator update")
+    p.add_argument("--gp_lambda", default="10", help="lambda for gradient penalty")
+    p.add_argument("--use_buffer", action="store_true", help="sample the critic's fake batch from a replay buffer")
+    p.add_argument("--buffer_n", default="20", help="replay buffer size in batches")
+    p.add_argument("--permute", action="store_true", help="permute real data along the individual axis")
+    p.add_argument("--label_smooth", action="store_true", help="label smooth the real data")
+    p.add_argument("--label_noise", default="0.05", help="upper bound of the label-smoothing noise")
+    p.add_argument("--mono_switch", action="store_true", help="switch some input sites to monomorphic")
+    p.add_argument("--normalize", action="store_true", help="normalize inputs to [-1, 1] for tanh")
+    p.add_argument("--shuffle_inds", action="store_true", help="shuffle individuals in each input alignment")
+    p.add_argument("--verbose", action="store_true", help="verbose output to log")
+    args = p.parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO)
+    if args.odir != "None":
+        if not os.path.exists(args.odir):
+            os.mkdir(args.odir)
+        else:   # the reference empties an existing output directory (line 428)
+            for entry in os.listdir(args.odir):
+                path = os.path.join(args.odir, entry)
+                shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
+    return args
+
+
+def state_dicts(trainer):
+    """(generator, discriminator) state_dicts with the reference modules' keys, shapes and dtypes."""
+    e = trainer.eng
+    g = {}
+    for k, v in e.G.p.items():
+        g[k] = v.detach().clone()
+        if k.endswith(".bias"):   # BatchNorm: running stats follow the affine pair
+            base = k[:-len(".bias")]
+            g[base + ".running_mean"] = e.Gbuf.p[base + ".running_mean"].detach().clone()
+            g[base + ".running_var"] = e.Gbuf.p[base + ".running_var"].detach().clone()
+            g[base + ".num_batches_tracked"] = torch.tensor(e.g_batches_tracked, dtype=torch.long)
+    d = {k: v.detach().clone() for k, v in e.D.p.items()}
+    return g, d
+
+
+def save_models(trainer, gen_path, disc_path):
+    """src/data_processing_v2.py:26-28: torch.save of the two state_dicts."""
+    g, d = state_dicts(trainer)
+    torch.save(g, gen_path)
+    torch.save(d, disc_path)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not args.use_cuda or not torch.cuda.is_available():
+        raise SystemExit("this trainer runs on an MI355X GPU: pass --use_cuda on a machine with a HIP device")
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+
+    latent, batch = int(args.latent_size), int(args.batch_size)
+    epochs, save_freq, critic_iter = int(args.epochs), int(args.save_freq), int(args.critic_iter)
+    lam, num_in = int(args.gp_lambda), int(args.num_in)
+    act = "sigmoid" if args.gen == "sigGen" else "tanh"
+    normalize = args.normalize or args.gen == "tanNorm"
+    if args.plot:
+        logging.warning("--plot: the evaluation figures are not part of this package; continuing without them")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+
+    data = DataGeneratorDisk(args.idir, num_in=num_in, batch_size=batch)
+    sites, pos = data.load_all()
+    if args.mono_switch:
+        sites, pos = switch_monomorphic(sites, pos, 0, 10)
+    if args.label_smooth:
+        hi = float(args.label_noise)
+        ey = torch.from_numpy(np.random.uniform(0.0, hi, tuple(sites.shape)).astype(np.float32))
+        sites = sites * (1 - ey) + hi * ey
+    trainer = FusedTrainer(HipOps(dev), batch, dev, loss=args.loss, act=act, lam=lam, critic_iter=critic_iter,
+                           seed=random.randrange(1 << 30), lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
+                           latent=latent)
+    import layers   # default PyTorch initialisation of the reference's layer types
+    g0 = (layers.DC_Generator_Leaky_Sig if act == "sigmoid" else layers.DC_Generator_Leaky_Tan)(64, latent, 0.1, 1, 4)
+    d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
+    trainer.eng.G.load({k: v for k, v in g0.state_dict().items() if k in trainer.eng.G.p})
+    trainer.eng.D.load(d0.state_dict())
+    trainer.set_pool(sites, pos, normalize=normalize)
+    if args.use_buffer:
+        trainer.enable_fake_buffer(int(args.buffer_n) * batch)
+    else:
+        trainer.use_graph = True
+
+    iters_per_epoch = max(1, (num_in // batch) // critic_iter)
+    for epoch in range(1, epochs + 1):
+        trainer.shuffle_pool(rows=args.permute or args.shuffle_inds)
+        for j in range(iters_per_epoch):
+            trainer.step()
+            if j % batch == 1:
+                w, d_real, d_fake, pen, g_loss = trainer.losses()
+                logging.info("Epoch:\t%d/%d Discriminator loss: %6.8f Generator loss: %6.8f d_real: %6.8f d_fake: %6.8f"
+                             % (epoch, epochs, w, g_loss, d_real, d_fake))
+        if save_freq != 0 and (epoch == 1 or epoch % save_freq == 0 or epoch == epochs):
+            save_models(trainer, os.path.join(args.odir, "generator_model_{0:04d}.pt".format(epoch)),
+                        os.path.join(args.odir, "discriminator_model_{0:04d}.pt".format(epoch)))
+
+
+if __name__ == "__main__":
+    main()
