@@ -11,9 +11,11 @@ the device.  Metric: train alignments/sec = critic_iter * global_batch * steps /
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (fp32 MFMA implicit-GEMM
-convolutions), timed with HIP events around its launches in an instrumented pass that follows the
-timed region; `cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step)
-on this box's host cores over a bounded sample.
+convolutions): after the timed region one iteration's launches are noted and every launch shape is
+timed with HIP events on the launch stream around back-to-back launches (eager per-launch events
+would time host launch gaps, and launches inside a replayed graph cannot carry events);
+`cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step) on this box's
+host cores over a bounded sample.
 """
 from __future__ import annotations
 
@@ -50,43 +52,55 @@ def synthetic_pool(n, seed):
     return torch.from_numpy(sites[:, None]), torch.from_numpy(pos[:, None])
 
 
-class TimedOps:
-    """Proxy around HipOps that brackets the conv-family launches with HIP events on the launch
-    stream and accumulates (calls, flops, events) per kernel + shape."""
+class RecordingOps:
+    """Proxy around HipOps that, while `recording`, notes every conv-family launch (kernel, shape,
+    the actual argument tensors) of an iteration so that each launch shape can be timed afterwards."""
     NAMES = ("conv_down", "conv_up", "conv_wgrad")
 
     def __init__(self, ops):
         self._ops = ops
-        self.records = {}
+        self.recording = False
+        self.calls = {}
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
         if name not in self.NAMES:
             return fn
 
-        def timed(*a, **k):
-            if name == "conv_down":
-                x, w = a[0], a[1]
-                n, cs, cl, hs = x.shape[0], w.shape[0], w.shape[1], x.shape[2] // 2
-            elif name == "conv_up":
-                y, w = a[0], a[1]
-                n, cs, cl, hs = y.shape[0], w.shape[0], w.shape[1], y.shape[2]
-            else:
-                ya, x = a[0], a[1]
-                n, cs, cl, hs = ya.shape[0], ya.shape[1], x.shape[1], ya.shape[2]
+        def wrapped(*a, **k):
+            if self.recording:
+                if name == "conv_down":
+                    x, w = a[0], a[1]
+                    n, cs, cl, hs = x.shape[0], w.shape[0], w.shape[1], x.shape[2] // 2
+                elif name == "conv_up":
+                    y, w = a[0], a[1]
+                    n, cs, cl, hs = y.shape[0], w.shape[0], w.shape[1], y.shape[2]
+                else:
+                    ya, x = a[0], a[1]
+                    n, cs, cl, hs = ya.shape[0], ya.shape[1], x.shape[1], ya.shape[2]
+                rec = self.calls.setdefault((name, n, cs, cl, hs), dict(count=0, args=(a, k)))
+                rec["count"] += 1
+            return fn(*a, **k)
+        return wrapped
+
+    def time_shapes(self, reps=20):
+        """Average duration of every recorded launch shape: HIP events on the launch stream around
+        `reps` back-to-back launches (the queue stays full, so host launch latency is not timed)."""
+        out = {}
+        for key, rec in self.calls.items():
+            a, k = rec["args"]
+            fn = getattr(self._ops, key[0])
+            for _ in range(3):
+                fn(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            fn(*a, **k)
+            for _ in range(reps):
+                fn(*a, **k)
             e.record()
-            key = (name, n, cs, cl, hs)
-            self.records.setdefault(key, []).append((s, e, 2.0 * n * cs * cl * 16 * hs * hs))
-        return timed
-
-    def summary(self):
-        out = {}
-        for key, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            out[key] = dict(calls=len(recs), ms=float(np.mean(ms)), total_ms=float(np.sum(ms)), flops=recs[0][2])
+            e.synchronize()
+            ms = s.elapsed_time(e) / reps
+            n, cs, cl, hs = key[1:]
+            out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=2.0 * n * cs * cl * 16 * hs * hs)
         return out
 
 
@@ -127,7 +141,7 @@ def main():
     ap.add_argument("--critic-iter", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-iters", type=int, default=3, help="instrumented iterations for per-kernel timing")
+    ap.add_argument("--profile-iters", type=int, default=20, help="back-to-back launches per shape for per-kernel timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +159,7 @@ def main():
     from pgan_trainer import FusedTrainer
 
     ops = HipOps(dev)
-    timed = TimedOps(ops)
+    timed = RecordingOps(ops)
     tr = FusedTrainer(timed, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
                       seed=1234, process_group=pg, rank=rank, world=world)
     from pgan_engine import disc_param_shapes, gen_param_shapes
@@ -164,11 +178,8 @@ def main():
     use_graph = (world == 1) and not args.no_graph
     step = tr.iteration
     if use_graph:
-        timed_names, TimedOps.NAMES = TimedOps.NAMES, ()     # no events inside the captured graph
         tr.capture()
-        TimedOps.NAMES = timed_names
         step = tr.replay
-    TimedOps.NAMES, saved = (), TimedOps.NAMES
     for _ in range(args.warmup):
         step()
 
@@ -191,13 +202,12 @@ def main():
         dt = float(tmax)
     losses = tr.losses()
 
-    # instrumented eager pass: HIP events around every conv-family launch
-    TimedOps.NAMES = saved
-    timed.records.clear()
-    for _ in range(args.profile_iters):
-        tr.iteration()
+    # per-kernel timing of the conv family: note one iteration's launches, then time each shape
+    timed.recording = True
+    tr.iteration()
+    timed.recording = False
     torch.cuda.synchronize()
-    summ = timed.summary()
+    summ = timed.time_shapes(args.profile_iters)
 
     if rank == 0:
         fam = {}
@@ -219,9 +229,10 @@ def main():
                             traffic=None,
                             avg_launch_us=round(f["total_ms"] * 1e3 / f["calls"], 2), launches=f["calls"],
                             flops_per_launch_avg=f["flops"] / f["calls"],
-                            measured=f"HIP events on the launch stream, {args.profile_iters} instrumented iterations "
-                                     f"after the timed region", families={k: dict(
-                                         share_ms_per_iter=round(v["total_ms"] / args.profile_iters, 3),
+                            measured=f"HIP events on the launch stream around {args.profile_iters} back-to-back launches "
+                                     f"of every launch shape of one iteration, after the timed region; per-launch "
+                                     f"average weighted by the shape's launches per iteration", families={k: dict(
+                                         share_ms_per_iter=round(v["total_ms"], 3),
                                          tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2)) for k, v in fam.items()},
                             per_shape=per_shape)
         nalign = args.critic_iter * args.batch * world * args.steps
