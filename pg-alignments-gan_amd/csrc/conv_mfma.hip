@@ -802,7 +802,38 @@ constexpr int FILL_WAVES = 2048;
 // tuning overrides (0 = choose from the launch size): see pgan_set_option
 int g_down_kg = 0;     // 1, 2, 4: K groups of the DOWN kernel
 int g_down_ks = 0;     // 1, 2: K split across blocks of the DOWN kernel (2 partial sums added atomically)
+int g_down_variant = 0;  // experiment: 1 = 128x64 tile, 2 = 64x128, 3 = 128x128 (2 / 2 / 4 accumulators per wave)
 int g_up_mode = 0;     // 1: all-phase 64x64 tiles; 2: phase-split, no K split; 3: phase-split, 2 K groups
+
+// Up to 4 independent row reductions in one launch (blockIdx.y selects the segment).
+struct RowSegs {
+    const float* part[4];
+    float* out[4];
+    int ld[4];
+    int C[4];
+};
+__global__ __launch_bounds__(256) void rows_sum_multi_kernel(RowSegs sg, int r0, int r1, int r2, int r3) {
+    __shared__ float sh[8][33];
+    const int seg = blockIdx.y;
+    const int C = sg.C[seg], ld = sg.ld[seg];
+    const float* part = sg.part[seg];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    if (blockIdx.x * 32 >= C) return;
+    float s = 0.f;
+    if (c < C) {
+        for (int r = r0 + ry; r < r1; r += 8) s += part[(int64_t)r * ld + c];
+        for (int r = r2 + ry; r < r3; r += 8) s += part[(int64_t)r * ld + c];
+    }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        sg.out[seg][c] = t;
+    }
+}
 
 template <int HS>
 int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl, hipStream_t st) {
@@ -811,6 +842,18 @@ int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl,
     const int grid = (Cs / BM) * PixTile<HS, BN>::ntiles(N);
     // Fewer than ~2 blocks per CU: split K over two blocks as well (two partial sums added onto a
     // zeroed output: the sum of two terms does not depend on their order).
+    if (g_down_variant == 1 && Cs % 128 == 0) {
+        conv_down_kernel<HS, 128, 64, 4, 1><<<(Cs / 128) * PixTile<HS, 64>::ntiles(N), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        return pgan_launch_status();
+    }
+    if (g_down_variant == 2) {
+        conv_down_kernel<HS, 64, 128, 8, 1><<<(Cs / 64) * PixTile<HS, 128>::ntiles(N), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        return pgan_launch_status();
+    }
+    if (g_down_variant == 3 && Cs % 128 == 0) {
+        conv_down_kernel<HS, 128, 128, 4, 1><<<(Cs / 128) * PixTile<HS, 128>::ntiles(N), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        return pgan_launch_status();
+    }
     const int ks = g_down_ks ? g_down_ks : ((grid < 512 && Cl >= 128) ? 2 : 1);
     const int waves = grid * 4 * ks;
     const int kg = g_down_kg ? g_down_kg : (waves >= FILL_WAVES ? 1 : (waves * 2 >= FILL_WAVES ? 2 : 4));
@@ -877,6 +920,7 @@ int pgan_set_option(const char* name, int value) {
     if (eq(name, a) && (value == 0 || value == 1 || value == 2 || value == 4)) { g_down_kg = value; return PGAN_OK; }
     if (eq(name, b) && value >= 0 && value <= 3) { g_up_mode = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 2) { g_down_ks = value; return PGAN_OK; }
+    if (eq(name, "down_variant") && value >= 0 && value <= 3) { g_down_variant = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 
@@ -950,6 +994,22 @@ int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r
                      hipStream_t st) {
     if (C <= 0 || ld < C) return PGAN_EINVAL;
     rows_sum_kernel<<<(C + 31) / 32, 256, 0, st>>>(part, ld, nullptr, out, C, r0, r1, r2, r3, accumulate);
+    return pgan_launch_status();
+}
+
+// nseg (<= 4) reductions out[i][c] = sum of part[i][r * ld[i] + c] over rows [r0,r1) and [r2,r3), one launch.
+int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const* out, const int* C, int nseg, int r0,
+                           int r1, int r2, int r3, hipStream_t st) {
+    if (nseg < 1 || nseg > 4) return PGAN_EINVAL;
+    RowSegs sg;
+    int cmax = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int k = i < nseg ? i : 0;
+        if (C[k] <= 0 || ld[k] < C[k]) return PGAN_EINVAL;
+        sg.part[i] = part[k]; sg.out[i] = out[k]; sg.ld[i] = ld[k]; sg.C[i] = C[k];
+        if (C[k] > cmax) cmax = C[k];
+    }
+    rows_sum_multi_kernel<<<dim3((cmax + 31) / 32, nseg), 256, 0, st>>>(sg, r0, r1, r2, r3);
     return pgan_launch_status();
 }
 

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u,
                                                     const float* __restrict__ a, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, float* __restrict__ d,
                                                     float* __restrict__ stats_b, float* __restrict__ pg,
-                                                    float* __restrict__ pb, int M, int HW, int C) {
+                                                    float* __restrict__ pb, int M, int HW, int C, int pld) {
     __shared__ double sh[2 * NT / 64];
     __shared__ float cg[512], cb[512];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u,
         stats_b[2 * n + 1] = mwx;
     }
     for (int c = tid; c < C; c += NT) {
-        pg[(int64_t)n * C + c] = cg[c];
-        pb[(int64_t)n * C + c] = cb[c];
+        pg[(int64_t)n * pld + c] = cg[c];
+        pb[(int64_t)n * pld + c] = cb[c];
     }
     for (int i = tid; i < M / 4; i += NT) {
         const int c = (i * 4) / HW;
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(NT) void gn_bwd2_kernel(const float* __restrict__ h
                                                      const float* __restrict__ a, const float* __restrict__ stats,
                                                      const float* __restrict__ stats_b, const float* __restrict__ stats_t,
                                                      const float* __restrict__ gamma, float* __restrict__ p,
-                                                     float* __restrict__ pg, float* __restrict__ pb, int M, int HW, int C) {
+                                                     float* __restrict__ pg, float* __restrict__ pb, int M, int HW, int C,
+                                                     int pld) {
     __shared__ double sh[3 * NT / 64];
     __shared__ float cg[512], cb[512];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(NT) void gn_bwd2_kernel(const float* __restrict__ h
     const float mwxd = r * (mwt - mw * tb - mwx * c_);
     const float kx = mQx + mwxd;
     for (int c = tid; c < C; c += NT) {
-        pg[(int64_t)n * C + c] = cg[c];
-        pb[(int64_t)n * C + c] = cb[c];
+        pg[(int64_t)n * pld + c] = cg[c];
+        pb[(int64_t)n * pld + c] = cb[c];
     }
     for (int i = tid; i < M / 4; i += NT) {
         const int c = (i * 4) / HW;
@@ -343,9 +344,9 @@ int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h,
 }
 
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
-                float* stats_b, float* pg, float* pb, int N, int C, int HW, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
-    gn_bwd_kernel<<<N, NT, 0, st>>>(u, h, a, stats, gamma, d, stats_b, pg, pb, C * HW, HW, C);
+                float* stats_b, float* pg, float* pb, int pld, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW) || pld < C) return PGAN_EINVAL;
+    gn_bwd_kernel<<<N, NT, 0, st>>>(u, h, a, stats, gamma, d, stats_b, pg, pb, C * HW, HW, C, pld);
     return pgan_launch_status();
 }
 
@@ -357,10 +358,10 @@ int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* sta
 }
 
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
-                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int N,
-                 int C, int HW, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
-    gn_bwd2_kernel<<<N, NT, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, C * HW, HW, C);
+                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
+                 int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW) || pld < C) return PGAN_EINVAL;
+    gn_bwd2_kernel<<<N, NT, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, C * HW, HW, C, pld);
     return pgan_launch_status();
 }
 

@@ -211,8 +211,10 @@ class Engine:
         self.dStat = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]    # mu, rstd
         self.dStatB = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(w), mean(w xhat)
         self.dStatT = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(t), mean(xhat t)
-        self.dPG = [None] + [torch.zeros(NT, D2_CH[k], **f) for k in range(1, 5)]  # per-sample gamma partials
-        self.dPB = [None] + [torch.zeros(NT, D2_CH[k], **f) for k in range(1, 5)]
+        # per-sample gamma | beta partial sums side by side, so one row reduction yields both gradients
+        self.dPGB = [None] + [torch.zeros(NT, 2 * D2_CH[k], **f) for k in range(1, 5)]
+        self.dPG = [None] + [self.dPGB[k][:, :D2_CH[k]] for k in range(1, 5)]
+        self.dPB = [None] + [self.dPGB[k][:, D2_CH[k]:] for k in range(1, 5)]
         self.G0 = torch.zeros(max(self.NP, B), 1, 64, 64, **f)   # input gradient of penalised samples / gen step
         self.d1A = [torch.zeros(2 * B, D1_CH[i + 1], D1_LEN[i + 1], **f) for i in range(3)]
         self.F1 = torch.zeros(2 * B, FEAT1, **f)
@@ -281,6 +283,19 @@ class Engine:
 
     def dgn(self, k):
         return (self.D.p[f"twod_conv_layers.{3 * (k - 1) + 1}.weight"], self.D.p[f"twod_conv_layers.{3 * (k - 1) + 1}.bias"])
+
+    def _gn_grad_pairs(self):
+        """[gamma_k | beta_k] gradient of each stage as one contiguous view of the flat gradient buffer
+        (the two tensors are adjacent there: sizes are multiples of the 64-float slice alignment)."""
+        if getattr(self, "_gnpairs", None) is None:
+            pairs = []
+            for k in range(1, 5):
+                n = f"twod_conv_layers.{3 * (k - 1) + 1}"
+                off, c = self.D.offsets[n + ".weight"], D2_CH[k]
+                assert self.D.offsets[n + ".bias"] == off + c
+                pairs.append(self.D.gflat[off:off + 2 * c])
+            self._gnpairs = pairs
+        return self._gnpairs
 
     def _d1d_params(self, store):
         cw = [store[f"oned_conv_layers.{3 * i}.weight"] for i in range(3)]
@@ -415,9 +430,7 @@ class Engine:
         if want_params:
             for k in range(1, 5):
                 o.conv_wgrad(self.dJ[k][:n], self.dH[k - 1][:n], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
-                gname = f"twod_conv_layers.{3 * (k - 1) + 1}"
-                o.rows_reduce(self.dPG[k], Dg[gname + ".weight"], 0, n, 0, 0)
-                o.rows_reduce(self.dPB[k], Dg[gname + ".bias"], 0, n, 0, 0)
+            o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), 0, n, 0, 0)
             o.head_wgrad(self.dH[4][:n], coef, Dg["out.weight"].view(-1)[:FEAT2])
             o.head_wgrad(self.F1[:n], coef, Dg["out.weight"].view(-1)[FEAT2:])
             o.head_wgrad(self.ones2B[:n], coef, Dg["out.bias"])
@@ -514,13 +527,8 @@ class Engine:
         # parameter gradients: one weight-gradient pass per stage over all 4B slots
         for k in range(1, 5):
             o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
-            gname = f"twod_conv_layers.{3 * (k - 1) + 1}"
-            if self.loss == "gp":
-                r = (0, 2 * B, NS, NT)
-            else:
-                r = (NS, NT, 0, 0)
-            o.rows_reduce(self.dPG[k], Dg[gname + ".weight"], *r)
-            o.rows_reduce(self.dPB[k], Dg[gname + ".bias"], *r)
+        r = (0, 2 * B, NS, NT) if self.loss == "gp" else (NS, NT, 0, 0)
+        o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), *r)
         o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
         self.side.join()
 

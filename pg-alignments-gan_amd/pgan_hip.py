@@ -38,9 +38,10 @@ _SIGS = {
     "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, I, I, I, P],
-    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
     "pgan_gn_jvp": [P, P, P, P, P, P, P, I, I, I, P],
-    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pgan_bn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
     "pgan_bn_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
@@ -84,6 +85,13 @@ def _ptr(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise PganError(f"expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def _rows_ptr(t: torch.Tensor):
+    """Pointer of a 2-D fp32 view whose rows are contiguous (columns of a wider row-major buffer)."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise PganError("expected a 2-D fp32 CUDA view with unit column stride")
     return t.data_ptr()
 
 
@@ -148,8 +156,19 @@ class HipOps:
     def rows_reduce(self, part, out, r0, r1, r2, r3, accumulate=False):
         C = part.shape[1]
         assert out.numel() == C
-        _check(_lib.pgan_rows_reduce(_ptr(part), C, _ptr(out), C, r0, r1, r2, r3, int(accumulate), _stream()),
-               "pgan_rows_reduce")
+        _check(_lib.pgan_rows_reduce(_rows_ptr(part), part.stride(0), _ptr(out), C, r0, r1, r2, r3, int(accumulate),
+                                     _stream()), "pgan_rows_reduce")
+
+    def rows_reduce_multi(self, parts, outs, r0, r1, r2, r3):
+        """outs[i][c] = sum of parts[i][r, c] over rows [r0,r1) and [r2,r3); up to 4 pairs, one launch."""
+        n = len(parts)
+        pa = (c_void_p * n)(*[_rows_ptr(t) for t in parts])
+        oa = (c_void_p * n)(*[_ptr(t) for t in outs])
+        ld = (c_int * n)(*[t.stride(0) for t in parts])
+        cc = (c_int * n)(*[t.shape[1] for t in parts])
+        for t, o in zip(parts, outs):
+            assert o.numel() == t.shape[1]
+        _check(_lib.pgan_rows_reduce_multi(pa, ld, oa, cc, n, r0, r1, r2, r3, _stream()), "pgan_rows_reduce_multi")
 
     # ---------------- GroupNorm family ----------------
     def gn_fwd(self, a, gamma, beta, h, stats):
@@ -159,8 +178,8 @@ class HipOps:
 
     def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
         N, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b), _ptr(pg),
-                                _ptr(pb), N, C, _hw(a), _stream()), "pgan_gn_bwd")
+        _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b),
+                                _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), N, C, _hw(a), _stream()), "pgan_gn_bwd")
 
     def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
         N, C = a.shape[0], a.shape[1]
@@ -170,8 +189,8 @@ class HipOps:
     def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
-                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _ptr(pg), _ptr(pb), N, C, _hw(a), _stream()),
-               "pgan_gn_bwd2")
+                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), N, C,
+                                 _hw(a), _stream()), "pgan_gn_bwd2")
 
     # ---------------- BatchNorm ----------------
     def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):

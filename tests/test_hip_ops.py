@@ -171,6 +171,34 @@ def test_groupnorm_family(hip, C, hs):
             assert float(pb_g.abs().max()) == 0.0
 
 
+def test_rows_reduce_multi(hip):
+    """gamma | beta partial sums written side by side by gn_bwd, then every stage reduced in one launch."""
+    rng = np.random.default_rng(11)
+    N = 7
+    parts, outs, wants = [], [], []
+    for C, hs in GN_SHAPES:
+        sh = (N, C, hs, hs)
+        a, u, gamma, beta = rnd(rng, *sh), rnd(rng, *sh), 1 + 0.2 * rnd(rng, C), 0.2 * rnd(rng, C)
+        h_g, st_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
+        hip.gn_fwd(*gpu(a, gamma, beta), h_g, st_g)
+        pgb = torch.full((N, 2 * C), float("nan"), device=DEV)
+        hip.gn_bwd(u.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), torch.zeros(sh, device=DEV),
+                   torch.zeros(N, 2, device=DEV), pgb[:, :C], pgb[:, C:])
+        pg_w, pb_w = torch.zeros(N, C, dtype=torch.float64), torch.zeros(N, C, dtype=torch.float64)
+        REF.gn_bwd(*d64(u, h_g.cpu(), a), st_g.cpu().double(), gamma.double(), torch.zeros(sh, dtype=torch.float64),
+                   torch.zeros(N, 2, dtype=torch.float64), pg_w, pb_w)
+        close("pgb", pgb, torch.cat([pg_w, pb_w], 1))
+        parts.append(pgb)
+        outs.append(torch.full((2 * C,), float("nan"), device=DEV))
+        wants.append(torch.cat([pg_w, pb_w], 1))
+    for rows in [(0, 2, 5, 7), (3, 7, 0, 0), (0, N, 0, 0)]:
+        hip.rows_reduce_multi(parts, outs, *rows)
+        for o, w in zip(outs, wants):
+            close("rows_reduce_multi", o, w[rows[0]:rows[1]].sum(0) + w[rows[2]:rows[3]].sum(0))
+    hip.rows_reduce_multi(parts[:2], outs[:2], 1, 2, 0, 0)
+    close("rows_reduce_multi2", outs[1], wants[1][1])
+
+
 @pytest.mark.parametrize("shape", [(6, 512, 4, 4), (6, 64, 32, 32), (6, 64, 4), (6, 8, 32)])
 def test_batchnorm(hip, shape):
     rng = np.random.default_rng(6)

@@ -119,6 +119,10 @@ class TorchOps:
         else:
             out.copy_(v)
 
+    def rows_reduce_multi(self, parts, outs, r0, r1, r2, r3):
+        for part, out in zip(parts, outs):
+            out.copy_(part[r0:r1].sum(0) + part[r2:r3].sum(0))
+
     # ---------------- linear head ----------------
     def head_fwd(self, h4, f1, w, b, score):
         """score[n] = <w[:8192], h4[n]> + <w[8192:], f1[n]> + b."""

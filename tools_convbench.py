@@ -14,7 +14,7 @@ def timeit(fn, reps=30):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-for N in (64, 192, 256, 320):
+for N in (64, 192, 256):
     for Cs, Cl, hs in LAYERS:
         fl = 2.0 * N * Cs * Cl * 16 * hs * hs
         y = torch.randn(N, Cs, hs, hs, device=dev); x = torch.randn(N, Cl, 2*hs, 2*hs, device=dev)
@@ -34,6 +34,15 @@ for N in (64, 192, 256, 320):
             set_option("down_kg", 0); set_option("down_ks", 0)
             us = timeit(lambda: ops.conv_down(x, w, y))
             print(f"down N={N:3d} hs={hs:2d} auto:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
+            for var in (1, 2, 3):
+                set_option("down_variant", var)
+                yy = torch.zeros_like(y); ops.conv_down(x, w, yy)
+                set_option("down_variant", 0); ops.conv_down(x, w, y)
+                err = float((yy - y).abs().max())
+                set_option("down_variant", var)
+                us = timeit(lambda: ops.conv_down(x, w, y))
+                print(f"down N={N:3d} hs={hs:2d} variant={var}:   {us:8.1f} us {fl/us/1e6:7.1f} TF  maxdiff {err:.1e}")
+            set_option("down_variant", 0)
         if which in ("all", "wgrad"):
             us = timeit(lambda: ops.conv_wgrad(y, x, dw))
             print(f"wgrd N={N:3d} hs={hs:2d}:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
