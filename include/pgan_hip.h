@@ -48,6 +48,19 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
 int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r1, int r2, int r3, int accumulate,
                      hipStream_t st);
 
+/* ---- The same convolutions evaluated on the bf16 matrix pipe with fp32 accuracy: every fp32 operand is split
+ * into three bf16 terms and a product is the sum of its six significant partial products, accumulated in
+ * fp32 (error below that of an fp32 multiply).  Weights are passed as prepared planes:
+ *   planes = device buffer of pgan_conv_x3_prep_bytes(Cs, Cl) bytes filled by pgan_conv_x3_prep(W, ...);
+ *   prepare again whenever W changes.  Same reference ops as pgan_conv_down / pgan_conv_up
+ *   (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32, no fused activation). */
+long long pgan_conv_x3_prep_bytes(int Cs, int Cl);
+int pgan_conv_x3_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
+int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
+int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st);
+/* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant"; 0 = by size) */
+int pgan_x3_set_option(const char* name, int value);
+
 /* up to 4 such reductions in one launch (the norm-parameter gradients of the four stages) */
 int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const* out, const int* C, int nseg, int r0,
                            int r1, int r2, int r3, hipStream_t st);

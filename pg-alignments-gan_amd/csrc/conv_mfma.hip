@@ -12,32 +12,10 @@
 // All tensors fp32, NCHW contiguous.  MFMA operand maps (32x32x2): lane l supplies
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of lane l is
 // D[i = (r&3) + 8(r>>2) + 4(l>>5)][j = l&31].
-#include "pgan_common.h"
+#include "conv_tiles.h"
 
 namespace {
-
-// A tile of BN consecutive S-side pixels in (n, oh, ow) order: either R rows of one sample or
-// SEG whole samples.
-template <int HS, int BN>
-struct PixTile {
-    static constexpr int WS = HS, PIX = HS * HS;
-    static constexpr int SEG = (BN >= PIX) ? BN / PIX : 1;
-    static constexpr int R = (BN >= PIX) ? HS : BN / WS;
-    static constexpr int TPS = (BN >= PIX) ? 1 : PIX / BN;
-    static_assert(BN % WS == 0, "tile must hold whole rows");
-    static_assert((BN >= PIX) ? (BN % PIX == 0) : (PIX % BN == 0), "tile/sample mismatch");
-    __host__ __device__ static int ntiles(int N) { return (BN >= PIX) ? (N + SEG - 1) / SEG : N * TPS; }
-    __device__ static void origin(int tile, int& n0, int& oh0) {
-        if (BN >= PIX) { n0 = tile * SEG; oh0 = 0; }
-        else { n0 = tile / TPS; oh0 = (tile % TPS) * R; }
-    }
-};
-
-__device__ __forceinline__ int xcd_remap(int b, int total) {
-    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
-    // logical tiles so tiles that share an operand panel hit the same L2.  Speed only.
-    return (total % 8 == 0) ? (b % 8) * (total / 8) + b / 8 : b;
-}
+using namespace pgan;
 
 // ------------------------------------------------------------------------------------------------
 // DOWN: GEMM M = Cs (BM per block), N = pixels (BN per block), K = Cl*16 (CLC channels per step)
@@ -187,6 +165,183 @@ __global__ __launch_bounds__(256 * KG) void conv_down_kernel(const float* __rest
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tm][tn][r] += src[((tm * TN + tn) * 16 + r) * 64];
         }
+    }
+
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
+        const int n = n0 + seg;
+        if (n >= N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float* dst = Y + (((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow;
+                if (gridDim.y > 1) atomicAdd(dst, acc[tm][tn][r]);
+                else *dst = acc[tm][tn][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DOWN, software-pipelined form.  A 32x32x2 fp32 MFMA occupies the matrix pipe for 64 cycles, so
+// everything else a wave has to do fits in its shadow if it is issued between the MFMAs instead of
+// in a phase of its own: LDS is double-buffered (one barrier per K chunk), the operands of step
+// s+1 are read before the MFMAs of step s issue, chunk k+1 goes from registers to the other LDS
+// buffer a few stores per step, and chunk k+2 is in flight from global memory into a second
+// register set for a whole chunk.  Halo / out-of-range elements load from a valid address and are
+// zeroed by a select, so the staging code has no branches.
+// ------------------------------------------------------------------------------------------------
+template <int HS, int BM, int BN, int CLC>
+__global__ __launch_bounds__(256) void conv_down_pipe_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                             float* __restrict__ Y, int N, int Cs, int Cl) {
+    using T = PixTile<HS, BN>;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
+    constexpr int SEG = T::SEG, R = T::R;
+    constexpr int PR = 2 * R + 2, PC = 2 * WS + 2, PCP = 3 * WS;    // columns PC.. of a patch row are padding
+    constexpr int CHS = SEG * PR * PCP;
+    constexpr int ALD = CLC * 16 + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PE = SEG * PR * PC, NQ = (PE + 255) / 256;
+    constexpr int AV = BM * CLC * 4 / 256;
+    constexpr int BUF = BM * ALD + CLC * CHS;
+    constexpr int S = CLC * 2;                 // MFMA steps per chunk: (channel, tap-row pair)
+    constexpr int NST = AV + CLC * NQ;         // staging stores per thread per chunk
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && AV >= 1 && PCP > PC, "tile shape");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nmt = Cs / BM, npt = T::ntiles(N);
+    const int b = xcd_remap(blockIdx.x, nmt * npt);
+    const int ptile = b / nmt, cs0 = (b % nmt) * BM;
+    int n0, oh0;
+    T::origin(ptile, n0, oh0);
+
+    uint32_t poff[NQ];
+    int loff[NQ];
+    bool pval[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 256 * q;
+        const int seg = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+        const int n = n0 + seg, ih = 2 * oh0 - 1 + pr, iw = pc - 1;
+        pval[q] = (e < PE) && n < N && ih >= 0 && ih < HL && iw >= 0 && iw < WL;
+        poff[q] = pval[q] ? (uint32_t)(((n * Cl * HL + ih) * WL) + iw) : 0u;
+        loff[q] = (e < PE) ? (seg * PR + pr) * PCP + pc : PC;     // threads past the patch write a padding slot
+    }
+    uint32_t aoff[AV];
+    int alds[AV];
+#pragma unroll
+    for (int q = 0; q < AV; ++q) {
+        const int idx = tid + 256 * q, row = idx / (CLC * 4), c4 = idx % (CLC * 4);
+        aoff[q] = (uint32_t)((cs0 + row) * Cl * 16 + c4 * 4);
+        alds[q] = row * ALD + c4 * 4;
+    }
+    f32x4 areg[2][AV];
+    float breg[2][CLC][NQ];
+    auto gload = [&](auto setc, int cl0) {
+        constexpr int ST = decltype(setc)::value;
+        const float* Wc = W + (int64_t)cl0 * 16;
+#pragma unroll
+        for (int q = 0; q < AV; ++q) areg[ST][q] = *reinterpret_cast<const f32x4*>(Wc + aoff[q]);
+#pragma unroll
+        for (int c = 0; c < CLC; ++c) {
+            const float* Xc = X + (int64_t)(cl0 + c) * HL * WL;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) breg[ST][c][q] = Xc[poff[q]];
+        }
+    };
+    // staging store number it (0 .. NST-1) of register set ST into the buffer at An / Bn
+    auto stage = [&](auto setc, auto itc, float* An, float* Bn) {
+        constexpr int ST = decltype(setc)::value, it = decltype(itc)::value;
+        if constexpr (it < AV) {
+            *reinterpret_cast<f32x4*>(An + alds[it]) = areg[ST][it];
+        } else {
+            constexpr int c = (it - AV) / NQ, q = (it - AV) % NQ;
+            Bn[c * CHS + loff[q]] = pval[q] ? breg[ST][c][q] : 0.f;
+        }
+    };
+
+    int abase[TM], bbase[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = (wm * (BM / 2) + tm * 32 + j) * ALD + h * 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
+        bbase[tn] = (seg * PR + 2 * ohl + h) * PCP + 2 * ow;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    f32x4 a[2][TM];
+    float2 b0[2][TN], b1[2][TN];
+    auto ldops = [&](const float* Ac, const float* Bc, auto sc) {
+        constexpr int s = decltype(sc)::value, c = s >> 1, khp = s & 1, set = s & 1;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a[set][tm] = *reinterpret_cast<const f32x4*>(Ac + abase[tm] + c * 16 + khp * 8);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float* p = Bc + c * CHS + bbase[tn] + khp * 2 * PCP;
+            b0[set][tn] = *reinterpret_cast<const float2*>(p);
+            b1[set][tn] = *reinterpret_cast<const float2*>(p + 2);
+        }
+    };
+
+    // gridDim.y > 1: the channel range is also split across blocks, which then add into a zeroed Y
+    const int nk = Cl / (CLC * (int)gridDim.y);       // even (checked by the launcher)
+    const int kc0 = blockIdx.y * nk;
+    auto chunk_cl = [&](int kc) { return (kc0 + (kc < nk ? kc : nk - 1)) * CLC; };
+
+    auto step_loop = [&](auto setc, const float* Ac, const float* Bc, float* An, float* Bn) {
+        ldops(Ac, Bc, IC<0>{});
+        [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+            ([&] {
+                constexpr int s = Ss, set = s & 1;
+                if constexpr (s + 1 < S) ldops(Ac, Bc, IC<s + 1>{});
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][0], b0[set][tn].x, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][1], b0[set][tn].y, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][2], b1[set][tn].x, acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][3], b1[set][tn].y, acc[tm][tn], 0, 0, 0);
+                    }
+                // this step's share of the staging stores
+                constexpr int lo = s * NST / S, hi = (s + 1) * NST / S;
+                [&]<int... Is>(std::integer_sequence<int, Is...>) {
+                    (stage(setc, IC<lo + Is>{}, An, Bn), ...);
+                }(std::make_integer_sequence<int, hi - lo>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, S>{});
+    };
+
+    // prologue: chunk 0 into buffer 0, chunk 1 into register set 0
+    gload(IC<0>{}, chunk_cl(0));
+    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (stage(IC<0>{}, IC<Is>{}, lds, lds + BM * ALD), ...);
+    }(std::make_integer_sequence<int, NST>{});
+    gload(IC<0>{}, chunk_cl(1));
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+        // even chunk: multiply buffer 0; set 0 (chunk kc+1) -> buffer 1; chunk kc+2 -> set 1
+        gload(IC<1>{}, chunk_cl(kc + 2));
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the chunk's MFMAs
+        step_loop(IC<0>{}, lds, lds + BM * ALD, lds + BUF, lds + BUF + BM * ALD);
+        __syncthreads();
+        gload(IC<0>{}, chunk_cl(kc + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        step_loop(IC<1>{}, lds + BUF, lds + BUF + BM * ALD, lds, lds + BM * ALD);
+        __syncthreads();
     }
 
 #pragma unroll
@@ -854,6 +1009,21 @@ int launch_down(const float* X, const float* W, float* Y, int N, int Cs, int Cl,
         conv_down_kernel<HS, 128, 128, 4, 1><<<(Cs / 128) * PixTile<HS, 128>::ntiles(N), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
         return pgan_launch_status();
     }
+    if (g_down_variant >= 4) {
+        const int ksp = g_down_ks ? g_down_ks : 1;
+        if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 16 >= (1ll << 31)) return PGAN_EINVAL;
+        if (ksp > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
+        if (g_down_variant == 4 && Cl % (8 * ksp) == 0)
+            conv_down_pipe_kernel<HS, 64, 64, 4><<<dim3((Cs / 64) * PixTile<HS, 64>::ntiles(N), ksp), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        else if (g_down_variant == 5 && Cs % 128 == 0 && Cl % (4 * ksp) == 0)
+            conv_down_pipe_kernel<HS, 128, 64, 2><<<dim3((Cs / 128) * PixTile<HS, 64>::ntiles(N), ksp), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        else if (g_down_variant == 6 && Cl % (8 * ksp) == 0)
+            conv_down_pipe_kernel<HS, 64, 128, 4><<<dim3((Cs / 64) * PixTile<HS, 128>::ntiles(N), ksp), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        else if (g_down_variant == 7 && Cs % 128 == 0 && Cl % (4 * ksp) == 0)
+            conv_down_pipe_kernel<HS, 128, 128, 2><<<dim3((Cs / 128) * PixTile<HS, 128>::ntiles(N), ksp), 256, 0, st>>>(X, W, Y, N, Cs, Cl);
+        else return PGAN_EINVAL;
+        return pgan_launch_status();
+    }
     const int ks = g_down_ks ? g_down_ks : ((grid < 512 && Cl >= 128) ? 2 : 1);
     const int waves = grid * 4 * ks;
     const int kg = g_down_kg ? g_down_kg : (waves >= FILL_WAVES ? 1 : (waves * 2 >= FILL_WAVES ? 2 : 4));
@@ -919,8 +1089,8 @@ int pgan_set_option(const char* name, int value) {
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, a) && (value == 0 || value == 1 || value == 2 || value == 4)) { g_down_kg = value; return PGAN_OK; }
     if (eq(name, b) && value >= 0 && value <= 3) { g_up_mode = value; return PGAN_OK; }
-    if (eq(name, "down_ks") && value >= 0 && value <= 2) { g_down_ks = value; return PGAN_OK; }
-    if (eq(name, "down_variant") && value >= 0 && value <= 3) { g_down_variant = value; return PGAN_OK; }
+    if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_down_ks = value; return PGAN_OK; }
+    if (eq(name, "down_variant") && value >= 0 && value <= 7) { g_down_variant = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 

@@ -589,6 +589,9 @@ class Engine:
                           st.step_dev)
         else:
             self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, st.step, lr, self.betas[0], self.betas[1], self.eps)
+        stale = getattr(self.ops, "invalidate_weight_planes", None)
+        if stale is not None:     # prepared copies of the convolution weights are rebuilt at their next use
+            stale()
 
     def adam_d(self) -> None:
         self._adam(self.D, self.lr_d)

@@ -36,6 +36,9 @@ _SIGS = {
     "pgan_conv_down": [P, P, P, I, I, I, I, P],
     "pgan_conv_up": [P, P, P, I, I, I, I, I, P],
     "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, P],
+    "pgan_conv_x3_prep": [P, P, I, I, P],
+    "pgan_conv_down_x3": [P, P, P, I, I, I, I, P],
+    "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, I, I, I, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
@@ -64,20 +67,29 @@ _SIGS = {
     "pgan_ct1d_wgrad": [P, P, P, I, I, I, I, P],
     "pgan_gemm": [P, P, P, I, I, I, I, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option"])
+EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
+                                "pgan_conv_x3_prep_bytes"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = c_int
 _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
-_lib.pgan_set_option.argtypes = [ctypes.c_char_p, c_int]
-_lib.pgan_set_option.restype = c_int
+_lib.pgan_conv_x3_prep_bytes.argtypes = [I, I]
+_lib.pgan_conv_x3_prep_bytes.restype = c_longlong
+for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option):
+    _fn.argtypes = [ctypes.c_char_p, c_int]
+    _fn.restype = c_int
 
 
 def set_option(name: str, value: int) -> None:
     """Kernel-variant override for tuning runs (0 = size-based choice)."""
     _check(_lib.pgan_set_option(name.encode(), int(value)), f"pgan_set_option({name}, {value})")
+
+
+def set_x3_option(name: str, value: int) -> None:
+    """Tile override of the bf16-pipe convolution kernels for tuning runs (0 = size-based choice)."""
+    _check(_lib.pgan_x3_set_option(name.encode(), int(value)), f"pgan_x3_set_option({name}, {value})")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -118,7 +130,8 @@ class HipOps:
     """Same method signatures as tests/torch_ops.TorchOps; every method writes into caller tensors."""
     name = "hip"
 
-    def __init__(self, device=None, ws_floats: int = 16 * 1024 * 1024, max_samples: int = 1024):
+    def __init__(self, device=None, ws_floats: int = 16 * 1024 * 1024, max_samples: int = 1024,
+                 precision: Optional[str] = None):
         if not torch.cuda.is_available():
             raise PganError("HipOps needs a GPU")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -127,18 +140,52 @@ class HipOps:
         self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
         self.max_samples = max_samples
         self._keep = []   # host-side arrays that must outlive an enqueue call
+        # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
+        # (fp32 accuracy); "fp32": the fp32 matrix pipe.  PGAN_CONV_PRECISION overrides the default.
+        self.precision = precision or os.environ.get("PGAN_CONV_PRECISION", "x3")
+        if self.precision not in ("x3", "fp32"):
+            raise PganError(f"unknown convolution precision {self.precision!r}")
+        # prepared bf16 planes per weight tensor; static_weights = the caller promises to call
+        # invalidate_weight_planes() after every weight update (otherwise planes are rebuilt per call)
+        self._planes = {}
+        self.static_weights = False
+
+    def invalidate_weight_planes(self):
+        for ent in self._planes.values():
+            ent[1] = False
+
+    def _weight_planes(self, w):
+        Cs, Cl = w.shape[0], w.shape[1]
+        key = (w.data_ptr(), Cs, Cl)
+        ent = self._planes.get(key)
+        if ent is None:
+            nbytes = _lib.pgan_conv_x3_prep_bytes(Cs, Cl)
+            ent = [torch.empty(nbytes, dtype=torch.uint8, device=self.device), False]
+            self._planes[key] = ent
+        if not (ent[1] and self.static_weights):
+            _check(_lib.pgan_conv_x3_prep(_ptr(w), ent[0].data_ptr(), Cs, Cl, _stream()), "pgan_conv_x3_prep")
+            ent[1] = True
+        return ent[0].data_ptr()
 
     # ---------------- conv family ----------------
     def conv_down(self, x, w, y):
         N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
         Cs, hs = w.shape[0], HL // 2
         assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
+        if self.precision == "x3" and Cl > 1:
+            _check(_lib.pgan_conv_down_x3(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, _stream()),
+                   "pgan_conv_down_x3")
+            return
         _check(_lib.pgan_conv_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down")
 
     def conv_up(self, y, w, x, act=0):
         N, Cs, hs = y.shape[0], y.shape[1], y.shape[2]
         Cl = w.shape[1]
         assert tuple(x.shape) == (N, Cl, 2 * hs, 2 * hs) and w.shape[0] == Cs
+        if self.precision == "x3" and Cl > 1 and act == 0:
+            _check(_lib.pgan_conv_up_x3(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, _stream()),
+                   "pgan_conv_up_x3")
+            return
         _check(_lib.pgan_conv_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, hs, act, _stream()), "pgan_conv_up")
 
     def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0):

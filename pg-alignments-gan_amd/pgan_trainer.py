@@ -36,6 +36,16 @@ class FusedTrainer:
         self.graph = None
         self.use_graph = False       # step(): capture on the first call, replay afterwards
         self.iterations = 0
+        # weights change only through the engine's Adam steps here, which mark prepared weight copies stale;
+        # anything else that writes parameters in place must call weights_changed()
+        if hasattr(ops, "static_weights"):
+            ops.static_weights = True
+
+    def weights_changed(self) -> None:
+        """Tell the op backend that parameters were written outside the engine's optimizer steps."""
+        if hasattr(self.ops, "invalidate_weight_planes"):
+            self.ops.invalidate_weight_planes()
+        self.graph = None
 
     def set_pool(self, sites: torch.Tensor, pos: torch.Tensor, normalize: bool = False) -> None:
         """Real alignments resident on the device: sites [P,1,64,64], positions [P,1,64], fp32.
@@ -145,6 +155,8 @@ class FusedTrainer:
         if self.world > 1:
             raise RuntimeError("graph capture is used on the single-GPU path only")
         torch.cuda.synchronize()
+        if hasattr(self.ops, "invalidate_weight_planes"):
+            self.ops.invalidate_weight_planes()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):     # one eager pass on the capture stream warms every kernel
@@ -153,6 +165,8 @@ class FusedTrainer:
         torch.cuda.synchronize()
         self.iterations += 1
         tracked, dstep, gstep = self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step
+        if hasattr(self.ops, "invalidate_weight_planes"):
+            self.ops.invalidate_weight_planes()      # so that the recorded iteration starts by preparing them
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._iteration_body()

@@ -59,12 +59,36 @@ def test_conv_down(hip, Cs, Cl, hs, N, kg):
     got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
     set_option("down_kg", kg % 10)           # 12 / 14: K also split over two blocks
     set_option("down_ks", 2 if kg >= 10 else (1 if kg else 0))
+    hip.precision = "fp32"
     try:
         hip.conv_down(*gpu(x, w), got)
     finally:
         set_option("down_kg", 0)
         set_option("down_ks", 0)
+        hip.precision = "x3"
     close("conv_down", got, want)
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
+@pytest.mark.parametrize("N", [5, 8])
+@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (2, 1), (2, 2), (3, 1), (4, 1), (4, 4)])
+def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
+    """Six-product bf16 split on the bf16 matrix pipe: same fp32 tolerance as the fp32-pipe kernels."""
+    from pgan_hip import set_x3_option
+    rng = np.random.default_rng(1)
+    x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+    REF.conv_down(*d64(x, w), want)
+    got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+    assert hip.precision == "x3"
+    set_x3_option("down_variant", variant)
+    set_x3_option("down_ks", ks)
+    try:
+        hip.conv_down(*gpu(x, w), got)
+    finally:
+        set_x3_option("down_variant", 0)
+        set_x3_option("down_ks", 0)
+    close("conv_down_x3", got, want)
 
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
@@ -78,11 +102,59 @@ def test_conv_up(hip, Cs, Cl, hs, N, mode):
     REF.conv_up(*d64(y, w), want)
     got = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
     set_option("up_mode", mode)
+    hip.precision = "fp32"
     try:
         hip.conv_up(*gpu(y, w), got)
     finally:
         set_option("up_mode", 0)
+        hip.precision = "x3"
     close("conv_up", got, want)
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
+@pytest.mark.parametrize("N", [5, 8])
+@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2)])
+def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
+    from pgan_hip import set_x3_option
+    rng = np.random.default_rng(2)
+    y, w = rnd(rng, N, Cs, hs, hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    want = torch.zeros(N, Cl, 2 * hs, 2 * hs, dtype=torch.float64)
+    REF.conv_up(*d64(y, w), want)
+    got = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
+    set_x3_option("up_variant", variant)
+    set_x3_option("up_ks", ks)
+    try:
+        hip.conv_up(*gpu(y, w), got)
+    finally:
+        set_x3_option("up_variant", 0)
+        set_x3_option("up_ks", 0)
+    close("conv_up_x3", got, want)
+
+
+def test_bf16_pipe_extremes(hip):
+    """The split keeps fp32's exponent range: tiny and huge magnitudes, exact zeros, and weights that are
+    updated in place between calls (prepared planes must follow them)."""
+    rng = np.random.default_rng(12)
+    N, Cs, Cl, hs = 3, 128, 64, 16
+    for scale_x, scale_w in [(1e-18, 1e-12), (1e15, 1e12), (1.0, 0.0)]:
+        x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs, scale=scale_x), rnd(rng, Cs, Cl, 4, 4, scale=scale_w)
+        want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+        REF.conv_down(*d64(x, w), want)
+        got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+        hip.conv_down(*gpu(x, w), got)
+        if scale_w == 0.0:
+            assert float(got.abs().max()) == 0.0
+        else:
+            close(f"conv_down_x3 scale {scale_x:g}", got, want)
+    x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    xg, wg = gpu(x, w)
+    got = torch.empty(N, Cs, hs, hs, device=DEV)
+    hip.conv_down(xg, wg, got)
+    wg.mul_(-2.0)                      # in-place update, same storage
+    hip.conv_down(xg, wg, got)
+    want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+    REF.conv_down(x.double(), -2.0 * w.double(), want)
+    close("conv_down_x3 after in-place weight update", got, want)
 
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)

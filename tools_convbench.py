@@ -26,7 +26,7 @@ for N in (64, 192, 256):
                 print(f"up   N={N:3d} hs={hs:2d} mode={mode}: {us:8.1f} us {fl/us/1e6:7.1f} TF")
             set_option("up_mode", 0)
         if which in ("all", "down"):
-            for ks in (1, 2):
+            for ks in ():
                 for kg in (1, 2, 4):
                     set_option("down_kg", kg); set_option("down_ks", ks)
                     us = timeit(lambda: ops.conv_down(x, w, y))
@@ -34,7 +34,7 @@ for N in (64, 192, 256):
             set_option("down_kg", 0); set_option("down_ks", 0)
             us = timeit(lambda: ops.conv_down(x, w, y))
             print(f"down N={N:3d} hs={hs:2d} auto:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
-            for var in (1, 2, 3):
+            for var in (1, 2, 3, 4, 5, 6, 7):
                 set_option("down_variant", var)
                 yy = torch.zeros_like(y); ops.conv_down(x, w, yy)
                 set_option("down_variant", 0); ops.conv_down(x, w, y)
@@ -43,6 +43,39 @@ for N in (64, 192, 256):
                 us = timeit(lambda: ops.conv_down(x, w, y))
                 print(f"down N={N:3d} hs={hs:2d} variant={var}:   {us:8.1f} us {fl/us/1e6:7.1f} TF  maxdiff {err:.1e}")
             set_option("down_variant", 0)
+        if which in ("x3",):
+            from pgan_hip import set_x3_option
+            refd = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=1)
+            refu = torch.nn.functional.conv_transpose2d(y.double(), w.double(), stride=2, padding=1)
+            ops.precision = "fp32"
+            ops.conv_down(x, w, y2 := torch.empty_like(y)); e = float((y2.double() - refd).norm() / refd.norm())
+            us = timeit(lambda: ops.conv_down(x, w, y2))
+            print(f"down N={N:3d} hs={hs:2d} fp32 mfma:       {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {e:.2e}")
+            ops.conv_up(y, w, x2 := torch.empty_like(x)); e = float((x2.double() - refu).norm() / refu.norm())
+            us = timeit(lambda: ops.conv_up(y, w, x2))
+            print(f"up   N={N:3d} hs={hs:2d} fp32 mfma:       {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {e:.2e}")
+            ops.precision = "x3"; ops.static_weights = True
+            us = timeit(lambda: (ops.invalidate_weight_planes(), ops._weight_planes(w)))
+            print(f"prep Cs={Cs} Cl={Cl}: {us:8.1f} us")
+            for var, ks in ((0, 0),):
+                set_x3_option("down_variant", var); set_x3_option("down_ks", ks)
+                yy = torch.full_like(y, float("nan"))
+                try:
+                    ops.conv_down(x, w, yy)
+                except Exception as ex:
+                    print(f"down N={N:3d} hs={hs:2d} x3 v={var} ks={ks}: {ex}"); continue
+                err = float((yy.double() - refd).norm() / refd.norm())
+                us = timeit(lambda: ops.conv_down(x, w, yy))
+                print(f"down N={N:3d} hs={hs:2d} x3 v={var} ks={ks}:     {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {err:.2e}")
+            set_x3_option("down_variant", 0); set_x3_option("down_ks", 0)
+            for var, ks in ((0, 0), (1, 1), (1, 2), (1, 4), (2, 1), (2, 2)):
+                set_x3_option("up_variant", var); set_x3_option("up_ks", ks)
+                xx = torch.full_like(x, float("nan"))
+                ops.conv_up(y, w, xx)
+                err = float((xx.double() - refu).norm() / refu.norm())
+                us = timeit(lambda: ops.conv_up(y, w, xx))
+                print(f"up   N={N:3d} hs={hs:2d} x3 v={var} ks={ks}:     {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {err:.2e}")
+            set_x3_option("up_variant", 0); set_x3_option("up_ks", 0)
         if which in ("all", "wgrad"):
             us = timeit(lambda: ops.conv_wgrad(y, x, dw))
             print(f"wgrd N={N:3d} hs={hs:2d}:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
