@@ -10,8 +10,10 @@
 // MFMAs (K = 2, 16 passes), and the fp32 pipe is power-limited to about 92 TFLOP/s on random data where
 // the bf16 pipe sustains about 1770.
 //
-// Weights enter as prepared bf16 planes (pgan_conv_x3_prep, once per weight update), activations are split
-// while they are staged into LDS.
+// Weights enter as prepared bf16 planes (pgan_conv_x3_prep, once per weight update) laid out so that one
+// wave's MFMA fragment is one contiguous 1 KB read: the waves load them straight from L2/L1 into registers,
+// one step ahead of their use, and only the activations (split while they are staged) go through LDS --
+// with both operands in LDS these kernels were bound by LDS bandwidth, not by the matrix pipe.
 //
 // Same operator definitions and tensor layouts as conv_mfma.hip (reference src/layers.py:441-463
 // Conv2d, :97-112 ConvTranspose2d).  Operand maps of the 32x32x16 MFMA: lane l supplies
@@ -61,9 +63,10 @@ __device__ __forceinline__ void mfma_x3(const u32x4 (&a)[3], const u32x4 (&b)[3]
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight preparation: W[Cs][Cl][16] fp32 -> bf16 planes in the two operand orders the kernels read:
-//   dn[p][cs][cl][tap]   (DOWN: rows cs, K = (cl, tap))
-//   up[p][tap][cl][cs]   (UP:   rows cl, K = cs at a fixed tap)
+// Weight preparation: W[Cs][Cl][16] fp32 -> bf16 planes in the two fragment orders the kernels read:
+//   dn[p][cl][cs][tap']           DOWN: rows cs, one K step = the 16 taps of channel cl, stored in the order
+//                                 the patch is read: tap' = 8(kh>>1) + 4(kw>>1) + 2(kh&1) + (kw&1)
+//   up[p][tap][cs/16][cl][cs%16]  UP:   rows cl, one K step = 16 cs at a fixed tap
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, uint16_t* __restrict__ dn,
                                                    uint16_t* __restrict__ up, int Cs, int Cl) {
@@ -84,41 +87,41 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        u32x4* d = reinterpret_cast<u32x4*>(dn + i * plane + ((size_t)cs * Cl + cl) * 16);
-        u32x4 lo = {pk[i][0], pk[i][1], pk[i][2], pk[i][3]}, hi = {pk[i][4], pk[i][5], pk[i][6], pk[i][7]};
+        // pk[i][2kh + (kw>>1)] holds taps (kh, kw even | odd): dword order (kh0,kw01) (kh1,kw01) (kh0,kw23) (kh1,kw23)
+        u32x4* d = reinterpret_cast<u32x4*>(dn + i * plane + ((size_t)cl * Cs + cs) * 16);
+        u32x4 lo = {pk[i][0], pk[i][2], pk[i][1], pk[i][3]}, hi = {pk[i][4], pk[i][6], pk[i][5], pk[i][7]};
         d[0] = lo;
         d[1] = hi;
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            up[i * plane + ((size_t)t * Cl + cl) * Cs + cs] = (uint16_t)(pk[i][t >> 1] >> (16 * (t & 1)));
+            up[i * plane + (((size_t)t * (Cs / 16) + cs / 16) * Cl + cl) * 16 + (cs & 15)] =
+                (uint16_t)(pk[i][t >> 1] >> (16 * (t & 1)));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // DOWN: GEMM M = Cs (BM per block), N = pixels (BN per block), K = Cl*16; one MFMA K step is one
-// input channel's 16 taps.  LDS holds, per bf16 plane, the weight tile [BM][CLC*16] and the input
-// patches [CLC][rows][cols] (two bf16 per dword).  Software pipeline: LDS double-buffered with one
-// barrier per chunk of CLC channels; chunk k+1 goes from registers to LDS (the activations are split
-// on the way) between the MFMAs of chunk k while chunk k+2 is in flight from global memory into a
-// second register set.
+// input channel's 16 taps.  Weight fragments come straight from global memory one channel ahead.
+// LDS holds, per bf16 plane, the input patches [CLC][row pair][column pair][2 rows] (two bf16 per dword, so
+// a lane's eight K values are 16 contiguous bytes), double-buffered
+// with one barrier per chunk of CLC channels: chunk k+1 goes from registers to LDS (split on the way)
+// between the MFMAs of chunk k while chunk k+2 is in flight from global memory into a second register set.
 // ------------------------------------------------------------------------------------------------
-template <int HS, int BM, int BN, int CLC, int ABL = 0>
+template <int HS, int BM, int BN, int CLC>
 __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
-    constexpr int PR = 2 * R + 2, PCW = WS + 1, RSW = PCW + 1;    // patch rows; dwords (column pairs) per row; row stride
+    constexpr int PR = 2 * R + 2, PCW = WS + 1, RSW = PCW + 1;    // patch rows; column pairs per row; their padded count
     constexpr int CHW = SEG * PR * RSW;                           // dwords per channel per plane
     constexpr int BPL = CLC * CHW;
-    constexpr int ALDW = CLC * 8 + 4, APL = BM * ALDW;
-    constexpr int BUF = 3 * APL + 3 * BPL;
+    constexpr int BUF = 3 * BPL;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PE = SEG * PR * PCW, NQ = (PE + 255) / 256;
-    constexpr int AG = 3 * BM * CLC * 2 / 256;  // 16-byte weight granules per thread per chunk
     constexpr int S = CLC * TM * TN;            // micro steps (six MFMAs each) per chunk
-    constexpr int NST = AG + CLC * NQ;          // staging items per thread per chunk
-    static_assert(BM % 64 == 0 && BN % 64 == 0 && AG >= 1 && (3 * BM * CLC * 2) % 256 == 0, "tile shape");
+    constexpr int NST = CLC * NQ;               // staging items per thread per chunk
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && CLC % 2 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,24 +147,12 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
         const uint32_t base = (uint32_t)((n * Cl * HL + ih) * WL + 2 * pw);
         off0[q] = val0[q] ? base - 1u : 0u;
         off1[q] = val1[q] ? base : 0u;
-        loff[q] = (e < PE) ? (seg * PR + pr) * RSW + pw : PCW;       // threads past the patch write a padding slot
+        // threads past the patch write a padding slot
+        loff[q] = (e < PE) ? ((seg * PR + pr) >> 1) * (2 * RSW) + 2 * pw + (pr & 1) : 2 * PCW;
     }
-    uint32_t aoff[AG];
-    int alds[AG];
-#pragma unroll
-    for (int q = 0; q < AG; ++q) {
-        const int g = tid + 256 * q;
-        const int plane = g / (BM * CLC * 2), rem = g % (BM * CLC * 2), row = rem / (CLC * 2), c = (rem >> 1) % CLC, half = rem & 1;
-        aoff[q] = (uint32_t)(plane * Cs * Cl * 16 + ((cs0 + row) * Cl + c) * 16 + half * 8);   // bf16 units
-        alds[q] = plane * APL + row * ALDW + c * 8 + half * 4;
-    }
-    u32x4 areg[2][AG];
     float breg[2][CLC][NQ][2];
     auto gload = [&](auto setc, int cl0) {
         constexpr int ST = decltype(setc)::value;
-        const uint16_t* Wc = WP + (int64_t)cl0 * 16;
-#pragma unroll
-        for (int q = 0; q < AG; ++q) areg[ST][q] = *reinterpret_cast<const u32x4*>(Wc + aoff[q]);
 #pragma unroll
         for (int c = 0; c < CLC; ++c) {
             const float* Xc = X + (int64_t)(cl0 + c) * HL * WL;
@@ -175,25 +166,22 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
     // staging item `it` of register set ST into buffer `buf`
     auto stage = [&](auto setc, auto itc, uint32_t* buf) {
         constexpr int ST = decltype(setc)::value, it = decltype(itc)::value;
-        if constexpr (it < AG) {
-            *reinterpret_cast<u32x4*>(buf + alds[it]) = areg[ST][it];
-        } else {
-            constexpr int c = (it - AG) / NQ, q = (it - AG) % NQ;
-            uint32_t p[3];
-            split3(val0[q] ? breg[ST][c][q][0] : 0.f, val1[q] ? breg[ST][c][q][1] : 0.f, p);
+        constexpr int c = it / NQ, q = it % NQ;
+        uint32_t p[3];
+        split3(val0[q] ? breg[ST][c][q][0] : 0.f, val1[q] ? breg[ST][c][q][1] : 0.f, p);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) buf[3 * APL + i * BPL + c * CHW + loff[q]] = p[i];
-        }
+        for (int i = 0; i < 3; ++i) buf[i * BPL + c * CHW + loff[q]] = p[i];
     };
 
-    int abase[TM], bbase[TN];
+    uint32_t abase[TM];
+    int bbase[TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) abase[tm] = (wm * (BM / 2) + tm * 32 + j) * ALDW + 4 * h;
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = (uint32_t)((cs0 + wm * (BM / 2) + tm * 32 + j) * 16 + 8 * h);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = wn * (BN / 2) + tn * 32 + j;
         const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
-        bbase[tn] = 3 * APL + (seg * PR + 2 * ohl + 2 * h) * RSW + ow;
+        bbase[tn] = (seg * (PR / 2) + ohl + h) * (2 * RSW) + 2 * ow;
     }
     f32x16 acc[TM][TN], acl[TM][TN];      // leading-term sums, correction-term sums
 #pragma unroll
@@ -204,18 +192,24 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; acl[tm][tn][r] = 0.f; }
 
     u32x4 a[2][TM][3], bo[2][TN][3];
-    auto ldops = [&](const uint32_t* buf, auto cc) {
-        constexpr int c = decltype(cc)::value, set = c & 1;
+    const size_t wplane = (size_t)Cl * Cs * 16;
+    auto aload = [&](auto setc, int cl) {          // weight fragments of channel cl
+        constexpr int set = decltype(setc)::value;
+        const uint16_t* Wc = WP + (size_t)cl * Cs * 16;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(buf + i * APL + abase[tm] + c * 8);
+            for (int i = 0; i < 3; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(Wc + i * wplane + abase[tm]);
+    };
+    auto ldops = [&](const uint32_t* buf, auto cc) {
+        constexpr int c = decltype(cc)::value, set = c & 1;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const uint32_t* p = buf + i * BPL + c * CHW + bbase[tn];
-                u32x4 v = {p[0], p[1], p[RSW], p[RSW + 1]};
+                const u32x2* p = reinterpret_cast<const u32x2*>(buf + i * BPL + c * CHW + bbase[tn]);
+                const u32x2 lo = p[0], hi = p[1];
+                u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
                 bo[set][tn][i] = v;
             }
     };
@@ -223,36 +217,38 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
     // gridDim.y > 1: the channel range is also split across blocks, which then add into a zeroed Y
     const int nk = Cl / (CLC * (int)gridDim.y);       // even (checked by the launcher)
     const int kc0 = blockIdx.y * nk;
+    const int cl_last = (kc0 + nk) * CLC - 1;
     auto chunk_cl = [&](int kc) { return (kc0 + (kc < nk ? kc : nk - 1)) * CLC; };
 
-    auto chunk = [&](auto setc, const uint32_t* cur, uint32_t* nxt) {
-        if constexpr (ABL != 3) ldops(cur, IC<0>{});
+    auto chunk = [&](auto setc, int clbase, const uint32_t* cur, uint32_t* nxt) {
+        ldops(cur, IC<0>{});
         static_for<S>([&](auto sc) {
             constexpr int s = decltype(sc)::value, c = s / (TM * TN), t = s % (TM * TN), tm = t / TN, tn = t % TN;
-            if constexpr (t == 0 && c + 1 < CLC && ABL != 3) ldops(cur, IC<c + 1>{});
-            if constexpr (ABL != 4) mfma_x3(a[c & 1][tm], bo[c & 1][tn], acc[tm][tn], acl[tm][tn]);
-            else acc[tm][tn][0] += __builtin_bit_cast(float, a[c & 1][tm][0][0] ^ bo[c & 1][tn][0][0]);
+            if constexpr (t == 0) {
+                if constexpr (c + 1 < CLC) ldops(cur, IC<c + 1>{});
+                aload(IC<(c + 1) & 1>{}, min(clbase + c + 1, cl_last));
+            }
+            mfma_x3(a[c & 1][tm], bo[c & 1][tn], acc[tm][tn], acl[tm][tn]);
             constexpr int lo = s * NST / S, hi = (s + 1) * NST / S;
-            if constexpr (ABL != 2) static_for<hi - lo>([&](auto ic) { stage(setc, IC<lo + decltype(ic)::value>{}, nxt); });
+            static_for<hi - lo>([&](auto ic) { stage(setc, IC<lo + decltype(ic)::value>{}, nxt); });
         });
     };
 
-    // prologue: chunk 0 into buffer 0, chunk 1 into register set 0
+    // prologue: chunk 0 into buffer 0, chunk 1 into register set 0, first weight fragments
     gload(IC<0>{}, chunk_cl(0));
+    aload(IC<0>{}, kc0 * CLC);
     static_for<NST>([&](auto ic) { stage(IC<0>{}, ic, lds); });
     gload(IC<0>{}, chunk_cl(1));
     __syncthreads();
-    if constexpr (ABL == 3) { ldops(lds, IC<0>{}); ldops(lds, IC<1>{}); }
-    if constexpr (ABL == 1) gload(IC<1>{}, chunk_cl(2));
     for (int kc = 0; kc < nk; kc += 2) {
-        if constexpr (ABL != 1) gload(IC<1>{}, chunk_cl(kc + 2));
+        gload(IC<1>{}, chunk_cl(kc + 2));
         __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the chunk's MFMAs
-        chunk(IC<0>{}, lds, lds + BUF);
-        if constexpr (ABL != 5) __syncthreads();
-        if constexpr (ABL != 1) gload(IC<0>{}, chunk_cl(kc + 3));
+        chunk(IC<0>{}, (kc0 + kc) * CLC, lds, lds + BUF);
+        __syncthreads();
+        gload(IC<0>{}, chunk_cl(kc + 3));
         __builtin_amdgcn_sched_barrier(0);
-        chunk(IC<1>{}, lds + BUF, lds);
-        if constexpr (ABL != 5) __syncthreads();
+        chunk(IC<1>{}, (kc0 + kc + 1) * CLC, lds + BUF, lds);
+        __syncthreads();
     }
 
 #pragma unroll
@@ -275,74 +271,57 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// UP: the four sub-pixel phases of a block tile (32 cl x BN S-grid pixels) go to the block's four
-// waves; a phase is a 2x2 stride-1 convolution, evaluated tap by tap with K = 16 cs per MFMA.
-// LDS per K step: weight granules [plane][tap][cl row][16 cs] and the S patch channel-innermost
-// [plane][patch pixel][16 cs]; the two 16-byte halves of a 32-byte row are swapped on every other
-// group of four rows so that the eight lanes of a b128 access phase hit distinct banks.
+// UP: the four sub-pixel phases of a tile go to four waves; NC such groups (different 32-cl row tiles)
+// share the block's S patch.  A phase is a 2x2 stride-1 convolution, evaluated tap by tap with
+// K = 16 cs per MFMA; a wave keeps the weight fragments of its four taps in registers and refills each
+// for the next K step right after using it.  LDS holds the S patch channel-innermost
+// [plane][patch pixel][16 cs], double-buffered, one barrier per K step; the two 16-byte halves of a
+// 32-byte pixel row are swapped on every other group of four pixels so that the eight lanes of a b128
+// access phase hit distinct banks.
 // Tap kh feeds output-row phase PH[kh] from S row a + DH[kh]:  kh 0:(1,+1) 1:(0,0) 2:(1,0) 3:(0,-1).
 // ------------------------------------------------------------------------------------------------
-template <int HS, int BN>
-__global__ __launch_bounds__(256) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
-                                                         float* __restrict__ X, int N, int Cs, int Cl) {
+template <int HS, int BN, int NC>
+__global__ __launch_bounds__(256 * NC) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
+                                                              float* __restrict__ X, int N, int Cs, int Cl) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
     constexpr int PR = R + 2, PC = WS + 2, NP = SEG * PR * PC;      // patch pixels
-    constexpr int BM = 32, TN = BN / 32;
-    constexpr int APL = 16 * BM * 8, BPL = NP * 8;                  // dwords per plane
-    constexpr int AG = 3 * 16 * BM * 2 / 256;                       // weight granules per thread per K step (12)
-    constexpr int NI = NP * 2, NQ = (NI + 255) / 256;               // (pixel, channel octet) items per thread
-    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * APL + 3 * BPL];
-    uint32_t* As = lds;
-    uint32_t* Bs = lds + 3 * APL;
+    constexpr int BM = 32 * NC, TN = BN / 32, NT = 256 * NC;
+    constexpr int BPL = NP * 8;                                     // dwords per plane
+    constexpr int NI = NP * 2, NQ = (NI + NT - 1) / NT;             // (pixel, channel octet) items per thread
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * 3 * BPL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ph = wave >> 1, pw = wave & 1, j = lane & 31, h = lane >> 5;
+    const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
     const int nmt = Cl / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
-    const int ptile = b / nmt, cl0 = (b % nmt) * BM;
+    const int ptile = b / nmt, cl0 = (b % nmt) * BM + wc * 32;
     int n0, oh0;
     T::origin(ptile, n0, oh0);
 
-    // weight granule g: (plane, tap, row, half)
-    uint32_t aoff[AG];
-    int alds[AG];
-#pragma unroll
-    for (int q = 0; q < AG; ++q) {
-        const int g = tid + 256 * q;
-        const int pt = g / (BM * 2), row = (g >> 1) % BM, half = g & 1;     // pt = plane * 16 + tap
-        aoff[q] = (uint32_t)((pt * Cl + cl0 + row) * Cs + half * 8);          // bf16 units
-        alds[q] = (pt * BM + row) * 8 + ((half ^ (row >> 2)) & 1) * 4;
-    }
     // patch item e: (pixel, octet)
     uint32_t boff[NQ];
     int blds[NQ];
     bool bval[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int e = tid + 256 * q, p = e >> 1, oct = e & 1;
+        const int e = tid + NT * q, p = e >> 1, oct = e & 1;
         const int seg = p / (PR * PC), rem = p % (PR * PC), pr = rem / PC, pc = rem % PC;
         const int n = n0 + seg, a = oh0 - 1 + pr, bb = pc - 1;
         bval[q] = (e < NI) && n < N && a >= 0 && a < HS && bb >= 0 && bb < WS;
         boff[q] = bval[q] ? (uint32_t)(((n * Cs + oct * 8) * HS + a) * WS + bb) : 0u;
         blds[q] = (e < NI) ? p * 8 + ((oct ^ (p >> 2)) & 1) * 4 : -1;
     }
-    u32x4 areg[AG];
     float breg[NQ][8];
     auto gload = [&](int cs0) {
-        const uint16_t* Wc = WP + cs0;
-#pragma unroll
-        for (int q = 0; q < AG; ++q) areg[q] = *reinterpret_cast<const u32x4*>(Wc + aoff[q]);
         const float* Yc = Y + (int64_t)cs0 * HS * WS;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int i = 0; i < 8; ++i) breg[q][i] = Yc[boff[q] + (bval[q] ? i * HS * WS : 0)];
     };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < AG; ++q) *reinterpret_cast<u32x4*>(As + alds[q]) = areg[q];
+    auto lstore = [&](uint32_t* Bs) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             uint32_t pk[3][4];
@@ -362,15 +341,17 @@ __global__ __launch_bounds__(256) void conv_up_x3_kernel(const float* __restrict
         }
     };
 
-    // this wave's four taps: LDS offsets of the weight granule and of each pixel tile's patch granule
-    int aofs[4], bofs[4][TN];
+    // this wave's four taps: global offsets of the weight fragment, LDS offsets of each pixel tile's patch granule
+    uint32_t aofs[4];
+    int bofs[4][TN];
+    const size_t wplane = (size_t)Cs * Cl * 16;
 #pragma unroll
     for (int th = 0; th < 2; ++th)
 #pragma unroll
         for (int tw = 0; tw < 2; ++tw) {
             const int kh = ph ? (th ? 0 : 2) : (th ? 3 : 1), dh = ph ? th : -th;
             const int kw = pw ? (tw ? 0 : 2) : (tw ? 3 : 1), dw = pw ? tw : -tw;
-            aofs[th * 2 + tw] = ((kh * 4 + kw) * BM + j) * 8 + ((h ^ (j >> 2)) & 1) * 4;
+            aofs[th * 2 + tw] = (uint32_t)(((kh * 4 + kw) * (Cs / 16) * Cl + cl0 + j) * 16 + 8 * h);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int pt = tn * 32 + j;
@@ -387,22 +368,34 @@ __global__ __launch_bounds__(256) void conv_up_x3_kernel(const float* __restrict
 
     // gridDim.y > 1: the cs range is split across blocks, which then add into a zeroed X
     const int nk = Cs / (16 * (int)gridDim.y), k0 = blockIdx.y * nk;
+    u32x4 a[4][3];
+    auto aload = [&](int t, int ks) {                 // weight fragments of tap t, K step ks
+        const uint16_t* Wk = WP + (size_t)ks * Cl * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
+    };
     gload(k0 * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aload(t, k0);
+    lstore(lds);
+    if (nk > 1) gload((k0 + 1) * 16);
+    __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        lstore();
-        __syncthreads();
-        if (kc + 1 < nk) gload((k0 + kc + 1) * 16);
+        const uint32_t* Bs = lds + (kc & 1) * 3 * BPL;
+        uint32_t* Bn = lds + ((kc + 1) & 1) * 3 * BPL;
+        const int knext = k0 + min(kc + 1, nk - 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            u32x4 a[3], bo[TN][3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + i * APL + aofs[t]);
+            u32x4 bo[TN][3];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) mfma_x3(a, bo[tn], acc[tn], acl[tn]);
+            for (int tn = 0; tn < TN; ++tn) mfma_x3(a[t], bo[tn], acc[tn], acl[tn]);
+            aload(t, knext);
+            if (t == 0 && kc + 1 < nk) lstore(Bn);                       // K step kc+1: registers -> other buffer
+            if (t == 1 && kc + 2 < nk) gload((k0 + kc + 2) * 16);        // K step kc+2: global -> registers
         }
         __syncthreads();
     }
@@ -431,40 +424,27 @@ int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs
     return pgan_launch_status();
 }
 
-int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0;   // tuning overrides (0 = by size)
-int g_ablate = 0, g_up_ks = 0;
+int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0, g_up_ks = 0;   // tuning overrides (0 = by size)
 
 template <int HS>
 int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st) {
     if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     int variant = g_dn_variant, ks = g_dn_ks;
     if (variant == 0 || ks < 1) {
-        // 128x64 tiles unless their grid leaves CUs idle; then split K over up to 4 blocks or halve the tile,
-        // whichever reaches ~2 blocks per CU with the smaller split
-        auto need = [&](int blocks) { return blocks >= 512 ? 1 : (blocks * 2 >= 512 ? 2 : 4); };
-        const int b2 = (Cs / 128) * PixTile<HS, 64>::ntiles(N), b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
-        int v = 2, k = need(b2);
-        if (Cs % 128 || need(b4) < k) { v = 4; k = need(b4); }
-        while (k > 1 && Cl % (2 * (v == 4 ? 4 : 2) * k)) k >>= 1;
+        // 128x64 tiles when they still give two blocks per CU, else 64x64 tiles (three blocks per CU);
+        // a grid that leaves CUs idle also splits K over 2 or 4 blocks
+        const int b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
+        int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
+        if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
+        while (k > 1 && Cl % (8 * k)) k >>= 1;
         if (variant == 0) variant = v;
         if (ks < 1) ks = k;
     }
     if (ks > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
-    if (g_ablate && HS == 16) {
-        const dim3 g((Cs / 128) * PixTile<HS, 64>::ntiles(N), ks);
-        switch (g_ablate) {
-            case 1: conv_down_x3_kernel<16, 128, 64, 2, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl); break;
-            case 2: conv_down_x3_kernel<16, 128, 64, 2, 2><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl); break;
-            case 3: conv_down_x3_kernel<16, 128, 64, 2, 3><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl); break;
-            case 4: conv_down_x3_kernel<16, 128, 64, 2, 4><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl); break;
-            case 5: conv_down_x3_kernel<16, 128, 64, 2, 5><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl); break;
-        }
-        return pgan_launch_status();
-    }
     switch (variant) {
-        case 1: return launch_down_tile<HS, 128, 128, 2>(X, WP, Y, N, Cs, Cl, ks, st);
-        case 2: return launch_down_tile<HS, 128, 64, 2>(X, WP, Y, N, Cs, Cl, ks, st);
-        case 3: return launch_down_tile<HS, 64, 128, 2>(X, WP, Y, N, Cs, Cl, ks, st);
+        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st);
+        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st);
+        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st);
         case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st);
         default: return PGAN_EINVAL;
     }
@@ -475,14 +455,21 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
     if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     const uint16_t* up = WP + (size_t)3 * Cs * Cl * 16;
-    const int variant = g_up_variant ? g_up_variant : 1;
-    const int blocks = (Cl / 32) * (variant == 2 ? PixTile<HS, 128>::ntiles(N) : PixTile<HS, 64>::ntiles(N));
-    int ks = g_up_ks ? g_up_ks : (blocks >= 512 ? 1 : (blocks * 2 >= 512 ? 2 : 4));
+    int variant = g_up_variant ? g_up_variant : 1;
+    if (variant >= 3 && Cl % 64) variant -= 2;
+    const int nc = variant >= 3 ? 2 : 1, bn = (variant & 1) ? 64 : 128;
+    const int blocks = (Cl / (32 * nc)) * (bn == 128 ? PixTile<HS, 128>::ntiles(N) : PixTile<HS, 64>::ntiles(N));
+    int ks = g_up_ks ? g_up_ks : 1;
     while (ks > 1 && Cs % (32 * ks)) ks >>= 1;
     if (ks > 1 && hipMemsetAsync(X, 0, sizeof(float) * (size_t)N * Cl * HS * HS * 4, st) != hipSuccess) return PGAN_ELAUNCH;
-    if (variant == 1) conv_up_x3_kernel<HS, 64><<<dim3(blocks, ks), 256, 0, st>>>(Y, up, X, N, Cs, Cl);
-    else if (variant == 2) conv_up_x3_kernel<HS, 128><<<dim3(blocks, ks), 256, 0, st>>>(Y, up, X, N, Cs, Cl);
-    else return PGAN_EINVAL;
+    const dim3 g(blocks, ks);
+    switch (variant) {
+        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        default: return PGAN_EINVAL;
+    }
     return pgan_launch_status();
 }
 
@@ -495,9 +482,8 @@ int pgan_x3_set_option(const char* name, int value) {
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, "down_variant") && value >= 0 && value <= 4) { g_dn_variant = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
-    if (eq(name, "ablate")) { g_ablate = value; return PGAN_OK; }
+    if (eq(name, "up_variant") && value >= 0 && value <= 4) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
-    if (eq(name, "up_variant") && value >= 0 && value <= 2) { g_up_variant = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 
