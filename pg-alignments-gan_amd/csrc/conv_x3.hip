@@ -455,10 +455,12 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
     if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     const uint16_t* up = WP + (size_t)3 * Cs * Cl * 16;
-    int variant = g_up_variant ? g_up_variant : 1;
-    if (variant >= 3 && Cl % 64) variant -= 2;
-    const int nc = variant >= 3 ? 2 : 1, bn = (variant & 1) ? 64 : 128;
-    const int blocks = (Cl / (32 * nc)) * (bn == 128 ? PixTile<HS, 128>::ntiles(N) : PixTile<HS, 64>::ntiles(N));
+    // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU
+    int variant = g_up_variant ? g_up_variant : ((Cl / 32) * PixTile<HS, 64>::ntiles(N) < 512 ? 5 : 1);
+    if ((variant == 3 || variant == 4) && Cl % 64) variant -= 2;
+    const int nc = (variant == 3 || variant == 4) ? 2 : 1, bn = variant == 5 ? 32 : ((variant & 1) ? 64 : 128);
+    const int blocks = (Cl / (32 * nc)) * (bn == 128 ? PixTile<HS, 128>::ntiles(N)
+                                                     : (bn == 64 ? PixTile<HS, 64>::ntiles(N) : PixTile<HS, 32>::ntiles(N)));
     int ks = g_up_ks ? g_up_ks : 1;
     while (ks > 1 && Cs % (32 * ks)) ks >>= 1;
     if (ks > 1 && hipMemsetAsync(X, 0, sizeof(float) * (size_t)N * Cl * HS * HS * 4, st) != hipSuccess) return PGAN_ELAUNCH;
@@ -468,6 +470,7 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
         case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
         case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
         case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
         default: return PGAN_EINVAL;
     }
     return pgan_launch_status();
@@ -482,7 +485,7 @@ int pgan_x3_set_option(const char* name, int value) {
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, "down_variant") && value >= 0 && value <= 4) { g_dn_variant = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
-    if (eq(name, "up_variant") && value >= 0 && value <= 4) { g_up_variant = value; return PGAN_OK; }
+    if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }

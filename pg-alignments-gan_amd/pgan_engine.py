@@ -590,8 +590,8 @@ class Engine:
         else:
             self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, st.step, lr, self.betas[0], self.betas[1], self.eps)
         stale = getattr(self.ops, "invalidate_weight_planes", None)
-        if stale is not None:     # prepared copies of the convolution weights are rebuilt at their next use
-            stale()
+        if stale is not None:     # prepared copies of this store's convolution weights are rebuilt at their next use
+            stale(st.flat)
 
     def adam_d(self) -> None:
         self._adam(self.D, self.lr_d)

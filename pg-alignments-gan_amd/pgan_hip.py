@@ -150,9 +150,17 @@ class HipOps:
         self._planes = {}
         self.static_weights = False
 
-    def invalidate_weight_planes(self):
-        for ent in self._planes.values():
-            ent[1] = False
+    def invalidate_weight_planes(self, within: Optional[torch.Tensor] = None):
+        """Mark prepared weight copies stale: all of them, or those whose weights live inside `within`."""
+        if within is None:
+            for ent in self._planes.values():
+                ent[1] = False
+            return
+        lo = within.data_ptr()
+        hi = lo + within.numel() * within.element_size()
+        for (ptr, _, _), ent in self._planes.items():
+            if lo <= ptr < hi:
+                ent[1] = False
 
     def _weight_planes(self, w):
         Cs, Cl = w.shape[0], w.shape[1]

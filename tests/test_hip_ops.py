@@ -113,7 +113,7 @@ def test_conv_up(hip, Cs, Cl, hs, N, mode):
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
 @pytest.mark.parametrize("N", [5, 8])
-@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2)])
+@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2), (3, 1), (4, 1), (5, 1)])
 def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
     from pgan_hip import set_x3_option
     rng = np.random.default_rng(2)
