@@ -831,56 +831,60 @@ __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restri
     }
 }
 
-// UP, Cl = 1 (+ optional sigmoid / tanh): block = one sample x 8 S rows; thread = S pixel -> 2x2 outputs.
+// UP, Cl = 1 (+ optional sigmoid / tanh).  Block = one sample x 4 S rows, 1024 threads = 8 channel groups x
+// 128 S pixels: the whole Cs-channel patch is staged once, every group sums its channels into the 2x2
+// outputs of its pixel, and the groups are combined through LDS.
 template <int HS>
-__global__ __launch_bounds__(256) void conv_up_c1_kernel(const float* __restrict__ Y, const float* __restrict__ W,
-                                                         float* __restrict__ X, int N, int Cs, int act) {
-    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 256 / WS, CSC = 16;
+__global__ __launch_bounds__(1024) void conv_up_c1_kernel(const float* __restrict__ Y, const float* __restrict__ W,
+                                                          float* __restrict__ X, int N, int Cs, int act) {
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 4, PX = RT * WS, NG = 1024 / PX;
     constexpr int PR = RT + 2, PC = WS + 2, PCP = PC | 1;
+    static_assert(PX * NG == 1024 && NG * 4 * PX <= 64 * PR * PCP, "block shape");
     __shared__ __attribute__((aligned(16))) float ws[64 * 16];
-    __shared__ float ys[CSC * PR * PCP];
+    __shared__ float ys[64 * PR * PCP];          // reused for the group partial sums
     const int tid = threadIdx.x;
     const int n = blockIdx.x / (HS / RT), a0 = (blockIdx.x % (HS / RT)) * RT;
-    for (int i = tid; i < Cs * 16; i += 256) ws[i] = W[i];
-    const int al = tid / WS, bl = tid % WS;
+    for (int i = tid; i < Cs * 16; i += 1024) ws[i] = W[i];
+    for (int e = tid; e < Cs * PR * PC; e += 1024) {
+        const int c = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
+        const int a = a0 - 1 + pr, b = pc - 1;
+        ys[(c * PR + pr) * PCP + pc] = (a >= 0 && a < HS && b >= 0 && b < WS)
+                                           ? Y[(((int64_t)n * Cs + c) * HS + a) * WS + b] : 0.f;
+    }
+    __syncthreads();
+    const int g = tid / PX, p = tid % PX, al = p / WS, bl = p % WS, cpg = Cs / NG;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cs; c0 += CSC) {
-        __syncthreads();
-        for (int e = tid; e < CSC * PR * PC; e += 256) {
-            const int c = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
-            const int a = a0 - 1 + pr, b = pc - 1;
-            ys[(c * PR + pr) * PCP + pc] = (a >= 0 && a < HS && b >= 0 && b < WS)
-                                               ? Y[(((int64_t)n * Cs + c0 + c) * HS + a) * WS + b] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int c = 0; c < CSC; ++c) {
-            float v[3][3];
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        float v[3][3];
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
+        for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) v[dh][dw] = ys[(c * PR + al + dh) * PCP + bl + dw];
-            const float* w = ws + (c0 + c) * 16;
+            for (int dw = 0; dw < 3; ++dw) v[dh][dw] = ys[(c * PR + al + dh) * PCP + bl + dw];
+        const float* w = ws + c * 16;
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh)
+        for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 4; ++kw) {
-                    const int ph = (kh == 0 || kh == 2) ? 1 : 0, dh = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
-                    const int pw = (kw == 0 || kw == 2) ? 1 : 0, dw = (kw == 0) ? 2 : (kw == 3 ? 0 : 1);
-                    acc[ph * 2 + pw] = fmaf(v[dh][dw], w[kh * 4 + kw], acc[ph * 2 + pw]);
-                }
-        }
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ph = (kh == 0 || kh == 2) ? 1 : 0, dh = (kh == 0) ? 2 : (kh == 3 ? 0 : 1);
+                const int pw = (kw == 0 || kw == 2) ? 1 : 0, dw = (kw == 0) ? 2 : (kw == 3 ? 0 : 1);
+                acc[ph * 2 + pw] = fmaf(v[dh][dw], w[kh * 4 + kw], acc[ph * 2 + pw]);
+            }
     }
-    if (act == 1) {
+    __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = 1.f / (1.f + expf(-acc[p]));
-    } else if (act == 2) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = tanhf(acc[p]);
+    for (int q = 0; q < 4; ++q) ys[(g * 4 + q) * PX + p] = acc[q];
+    __syncthreads();
+    if (g < 2) {     // group g finishes output-row phase g of its pixel: both column phases, one float2
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 0; k < NG; ++k) {     // fixed order: the sum does not depend on timing
+            s0 += ys[(k * 4 + g * 2) * PX + p];
+            s1 += ys[(k * 4 + g * 2 + 1) * PX + p];
+        }
+        if (act == 1) { s0 = 1.f / (1.f + expf(-s0)); s1 = 1.f / (1.f + expf(-s1)); }
+        else if (act == 2) { s0 = tanhf(s0); s1 = tanhf(s1); }
+        float* o = X + ((int64_t)n * HL + 2 * (a0 + al) + g) * WL + 2 * bl;
+        *reinterpret_cast<float2*>(o) = make_float2(s0, s1);
     }
-    float* o = X + ((int64_t)n * HL + 2 * (a0 + al)) * WL + 2 * bl;
-    *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[1]);
-    *reinterpret_cast<float2*>(o + WL) = make_float2(acc[2], acc[3]);
 }
 
 // WGRAD, Cl = 1: block = (sample, group of 16 cs); wave = 4 cs; lanes sweep the sample's pixels.
@@ -1115,8 +1119,8 @@ int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int 
 int pgan_conv_up(const float* S, const float* W, float* L, int N, int Cs, int Cl, int hs, int act, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
     if (Cl == 1) {
-        if (hs != 32 || Cs > 64 || Cs % 16) return PGAN_EINVAL;
-        conv_up_c1_kernel<32><<<N * (32 / 8), 256, 0, st>>>(S, W, L, N, Cs, act);
+        if (hs != 32 || Cs > 64 || Cs % 8) return PGAN_EINVAL;
+        conv_up_c1_kernel<32><<<N * (32 / 4), 1024, 0, st>>>(S, W, L, N, Cs, act);
         return pgan_launch_status();
     }
     if (act != 0) return PGAN_EINVAL;

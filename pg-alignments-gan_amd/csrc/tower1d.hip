@@ -317,6 +317,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
         }
 }
 
+// C[M,N] = A[M,K] B[K,N] for short, wide products (the generators' first layers: M = batch, K = latent):
+// one wave per 32x32 tile of C on the fp32 matrix pipe, operands straight from global memory (A is tiny
+// and stays in cache, B rows are read coalesced).  M % 32 == N % 32 == K % 8 == 0.
+__global__ __launch_bounds__(256) void gemm_nn_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                           float* __restrict__ C, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave, ntn = N / 32;
+    if (tile >= (M / 32) * ntn) return;
+    const int m0 = (tile / ntn) * 32, n0 = (tile % ntn) * 32;
+    const float* a = A + (int64_t)(m0 + j) * K + h;
+    const float* b = Bm + (int64_t)h * N + n0 + j;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; k += 8) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = a[k + 2 * q]; bv[q] = b[(int64_t)(k + 2 * q) * N]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        C[(int64_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * h) * N + n0 + j] = acc[r];
+}
+
 D1Params make_params(const float* const* p) {
     D1Params P;
     for (int i = 0; i < 3; ++i) {
@@ -377,6 +403,11 @@ int pgan_ct1d_wgrad(const float* ya, const float* x, float* dw, int N, int Cs, i
 // C[M,N] = A[M,K] B[K,N]  (transa = 0)  or  A[K,M]^T B[K,N]  (transa = 1); all row-major fp32.
 int pgan_gemm(const float* A, const float* B, float* C, int M, int N, int K, int transa, hipStream_t st) {
     if (M <= 0 || N <= 0 || K <= 0) return PGAN_EINVAL;
+    if (!transa && M % 32 == 0 && N % 32 == 0 && K % 8 == 0 && M <= 256) {
+        const int tiles = (M / 32) * (N / 32);
+        gemm_nn_mfma_kernel<<<(tiles + 3) / 4, 256, 0, st>>>(A, B, C, M, N, K);
+        return pgan_launch_status();
+    }
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     if (transa) gemm_kernel<true><<<grid, 256, 0, st>>>(A, B, C, M, N, K);
     else gemm_kernel<false><<<grid, 256, 0, st>>>(A, B, C, M, N, K);

@@ -199,6 +199,7 @@ class Engine:
                     v.fill_(1.0)
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
         self.side = SideStream(device)
+        self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
 
         NT = self.NT
         # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
@@ -521,12 +522,15 @@ class Engine:
             o.gn_bwd2(hbar, self.dU[k][pl:ph], self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph],
                       self.dStat[k][pl:ph], self.dStatB[k][pl:ph], self.dStatT[k][NS:NT], gw_k,
                       self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT])
+            # stage k's adjoints are complete over all 4B slots: its weight-gradient pass (one per stage,
+            # over all slots) runs on its own stream beside the rest of the chain
+            self.wside.fork()
+            with self.wside:
+                o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
             if k > 1:
                 o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT])
                 hbar = self.dU[k - 1][NS:NT]
-        # parameter gradients: one weight-gradient pass per stage over all 4B slots
-        for k in range(1, 5):
-            o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
+        self.wside.join()
         r = (0, 2 * B, NS, NT) if self.loss == "gp" else (NS, NT, 0, 0)
         o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), *r)
         o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
