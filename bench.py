@@ -10,8 +10,11 @@ the device.  Metric: train alignments/sec = critic_iter * global_batch * steps /
   python bench.py --gpus 1 --steps 50 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (fp32 MFMA implicit-GEMM
-convolutions): after the timed region one iteration's launches are noted and every launch shape is
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (implicit-GEMM convolutions;
+DOWN and UP run on the bf16 matrix pipe as six exact partial products per fp32 product, WGRAD on the fp32
+matrix pipe): `achieved` counts the MFMA flops the family executes on its pipe (six times the algorithmic
+fp32 flops on the bf16 pipe) against that pipe's dense peak; `algorithmic_tflops` is the fp32-equivalent
+rate.  After the timed region one iteration's launches are noted and every launch shape is
 timed with HIP events on the launch stream around back-to-back launches (eager per-launch events
 would time host launch gaps, and launches inside a replayed graph cannot carry events);
 `cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step) on this box's
@@ -36,7 +39,11 @@ F_G = 205_703_168          # generator forward FLOP / sample
 FLOP_PER_ALIGNMENT = {"gp": (5 * (F_G + 12 * F_D) + 3 * F_G + 2 * F_D) / 5.0}
 FLOP_PER_ALIGNMENT["div"] = FLOP_PER_ALIGNMENT["gp"]
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense
 PEAK_HBM_GBS = 8000.0
+# sustained by a register-only MFMA loop on random operands on this part (tools/mfma_peak.hip,
+# tools/mfma_bf16_peak.hip): the clocks drop under data-dependent power
+SUSTAINED_RANDOM_TFLOPS = {"fp32": 92.0, "bf16": 1770.0}
 
 
 def synthetic_pool(n, seed):
@@ -57,10 +64,18 @@ class RecordingOps:
     the actual argument tensors) of an iteration so that each launch shape can be timed afterwards."""
     NAMES = ("conv_down", "conv_up", "conv_wgrad")
 
+    _OWN = ("_ops", "recording", "calls")
+
     def __init__(self, ops):
         self._ops = ops
         self.recording = False
         self.calls = {}
+
+    def __setattr__(self, name, value):        # settings made through the proxy reach the real backend
+        if name in self._OWN:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self._ops, name, value)
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
@@ -217,29 +232,54 @@ def main():
             f["flops"] += r["flops"] * r["calls"]
             f["calls"] += r["calls"]
         dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
+        x3 = getattr(ops, "precision", "fp32") == "x3"
+        pipe = {k: ("bf16" if (x3 and k != "conv_wgrad") else "fp32") for k in fam}
         roofline = None
         if dom:
             f = fam[dom]
-            ach = f["flops"] / (f["total_ms"] * 1e-3) / 1e12
+            alg = f["flops"] / (f["total_ms"] * 1e-3) / 1e12
+            mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if pipe[dom] == "bf16" else (1.0, PEAK_FP32_MFMA_TFLOPS)
+            ach = alg * mult
             per_shape = {f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]":
                          dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
                               tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in sorted(summ.items())}
-            roofline = dict(bound="mfma", kernel=f"{dom}_kernel (fp32 MFMA implicit GEMM)", achieved=round(ach, 3),
-                            peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                            traffic=None,
+            # HBM traffic of the family's largest launch shape from the committed PMC passes (bytes per launch)
+            traffic, traffic_of = None, None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                big = max((k for k in summ if k[0] == dom), key=lambda k: summ[k]["flops"])
+                key = f"{big[0]}[N={big[1]},Cs={big[2]},Cl={big[3]},hs={big[4]}]"
+                if key in pm:
+                    traffic = (pm[key]["FETCH_SIZE_KB"] + pm[key]["WRITE_SIZE_KB"]) * 1024
+                    traffic_of = key
+            except (OSError, ValueError):
+                pass
+            kname = {"conv_up": "conv_up_x3_kernel", "conv_down": "conv_down_x3_kernel"}.get(dom, dom + "_kernel") \
+                if pipe[dom] == "bf16" else dom + "_kernel"
+            roofline = dict(bound="mfma", kernel=f"{kname} ({pipe[dom]} matrix pipe, implicit GEMM)",
+                            achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                            traffic=traffic, traffic_shape=traffic_of,
+                            algorithmic_tflops=round(alg, 3),
+                            executed_per_algorithmic_flop=mult,
+                            sustained_on_random_operands=SUSTAINED_RANDOM_TFLOPS[pipe[dom]],
+                            frac_of_sustained=round(ach / SUSTAINED_RANDOM_TFLOPS[pipe[dom]], 4),
                             avg_launch_us=round(f["total_ms"] * 1e3 / f["calls"], 2), launches=f["calls"],
                             flops_per_launch_avg=f["flops"] / f["calls"],
                             measured=f"HIP events on the launch stream around {args.profile_iters} back-to-back launches "
                                      f"of every launch shape of one iteration, after the timed region; per-launch "
                                      f"average weighted by the shape's launches per iteration", families={k: dict(
-                                         share_ms_per_iter=round(v["total_ms"], 3),
-                                         tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2)) for k, v in fam.items()},
+                                         share_ms_per_iter=round(v["total_ms"], 3), pipe=pipe[k],
+                                         algorithmic_tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
+                                         for k, v in fam.items()},
                             per_shape=per_shape)
         nalign = args.critic_iter * args.batch * world * args.steps
         value = nalign / dt
         out = dict(metric="train alignments/sec (WGAN-GP step, 64x64)", value=round(value, 2), unit="alignments/sec",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   arithmetic=("fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
+                               "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe, weight "
+                               "gradients on the fp32 matrix pipe" if x3 else "fp32 throughout (fp32 matrix pipe)"),
                    config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
                                         f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
                                global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,

@@ -1,6 +1,6 @@
 import csv, glob, sys, collections
 tag = sys.argv[1]
-for part in "abc":
+for part in "abcfw":
     fs = glob.glob(f'gpurun_out/{tag}_{part}/*/*counter_collection.csv')
     if not fs: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
