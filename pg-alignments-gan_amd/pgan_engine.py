@@ -200,6 +200,7 @@ class Engine:
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
         self.side = SideStream(device)
         self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
+        self.gside = SideStream(device)     # generator forwards made one critic step ahead (FusedTrainer)
 
         NT = self.NT
         # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
@@ -319,6 +320,12 @@ class Engine:
             self._gen_forward_1d(out_p)
         self._gen_forward_2d(out_s)
         self.side.join()
+
+    def gen_forward_resident(self, out_s: torch.Tensor, out_p: torch.Tensor) -> None:
+        """G(z) for the z already in self.Z, both towers on the current stream."""
+        self.g_batches_tracked += 1
+        self._gen_forward_1d(out_p)
+        self._gen_forward_2d(out_s)
 
     def _gen_forward_2d(self, out_s: torch.Tensor) -> None:
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
@@ -549,23 +556,27 @@ class Engine:
         self.Z.copy_(z.reshape(self.B, self.latent))
         self.generator_grads_resident()
 
-    def generator_grads_resident(self) -> None:
-        """generator_grads with z already in self.Z."""
+    def generator_grads_resident(self, forward_done: bool = False) -> None:
+        """generator_grads with z already in self.Z (forward_done: G(z) is already in gXs / gXp with its
+        activations in the generator workspace, from gen_forward_resident(self.gXs, self.gXp))."""
         o, B = self.ops, self.B
         Dp = self.D.p
         cw, cb, gw, gb = self._d1d_params(Dp)
         a1 = [a[:B] for a in self.d1A]
-        self.g_batches_tracked += 1
+        if not forward_done:
+            self.g_batches_tracked += 1
         self.side.fork()
         with self.side:   # positions: G 1-D forward, D 1-D forward, D 1-D input gradient, G 1-D backward
-            self._gen_forward_1d(self.gXp)
+            if not forward_done:
+                self._gen_forward_1d(self.gXp)
             self.P0[:B].copy_(self.gXp)
             o.d1d_fwd(self.P0[:B], cw, cb, gw, gb, a1, self.F1[:B])
             self.side.set_mark()
             o.d1d_bwd(self.P0[:B], cw, cb, gw, gb, a1, self.coef_gen, Dp["out.weight"].view(-1)[FEAT2:],
                       None, None, None, None, self.dP0)
             self._gen_backward_1d(self.gXp, self.dP0)
-        self._gen_forward_2d(self.gXs)
+        if not forward_done:
+            self._gen_forward_2d(self.gXs)
         self.X0[:B].copy_(self.gXs)
         self._d_forward2d(0, B)
         self.side.wait_mark()

@@ -129,18 +129,38 @@ class FusedTrainer:
             self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
     def _iteration_body(self) -> None:
+        """The generator's weights do not change during the critic steps, so every generator forward
+        (a chain of small launches) is made one step ahead on its own stream, beside the previous
+        critic step's large kernels: fakes alternate between two buffers, and the generator step's own
+        forward runs beside the last critic step.  z is still drawn in the reference's order."""
         e, o = self.eng, self.ops
-        B = e.B
-        for _ in range(self.critic_iter):
-            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
+        B, gs = e.B, e.gside
+        if getattr(self, "fk_s", None) is None:
+            self.fk_s = [torch.zeros(B, 1, 64, 64, device=self.dev) for _ in range(2)]
+            self.fk_p = [torch.zeros(B, 1, 64, device=self.dev) for _ in range(2)]
+        gs.fork()
+        with gs:
             o.philox(e.Z, self.rng_z, True)
+            e.gen_forward_resident(self.fk_s[0], self.fk_p[0])
+        for i in range(self.critic_iter):
+            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
             if e.loss == "gp":
                 o.philox(e.tbuf, self.rng_t, False)
-            e.critic_grads_resident()
+            gs.join()                                   # this step's fakes are complete
+            e.X0[B:2 * B].copy_(self.fk_s[i & 1])
+            e.P0[B:2 * B].copy_(self.fk_p[i & 1])
+            gs.fork()
+            with gs:                                    # next forward, beside this critic step
+                o.philox(e.Z, self.rng_z, True)
+                if i + 1 < self.critic_iter:
+                    e.gen_forward_resident(self.fk_s[(i + 1) & 1], self.fk_p[(i + 1) & 1])
+                else:
+                    e.gen_forward_resident(e.gXs, e.gXp)
+            e.critic_grads_resident(run_generator=False)
             self._allreduce(e.D.gflat)
             e.adam_d()
-        o.philox(e.Z, self.rng_z, True)
-        e.generator_grads_resident()
+        gs.join()
+        e.generator_grads_resident(forward_done=True)
         self._allreduce(e.G.gflat)
         e.adam_g()
 
