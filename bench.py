@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=20, help="back-to-back launches per shape for per-kernel timing")
+    ap.add_argument("--no-fp32-pipe", action="store_true", help="skip the side measurement with every convolution on the fp32 matrix pipe")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,22 +174,27 @@ def main():
     from pgan_hip import HipOps
     from pgan_trainer import FusedTrainer
 
+    from pgan_engine import disc_param_shapes, gen_param_shapes
+    ps, pp = synthetic_pool(4096, 20260 + 1 + rank)
+
+    def make_trainer(backend):
+        t = FusedTrainer(backend, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
+                         seed=1234, process_group=pg, rank=rank, world=world)
+        gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
+        for store, shapes in ((t.eng.G, gen_param_shapes()), (t.eng.D, disc_param_shapes())):
+            for k, sh in shapes.items():
+                if len(sh) == 1:
+                    v = torch.ones(sh) if k.endswith("weight") and not k.startswith("out") else torch.zeros(sh)
+                else:
+                    fan = int(np.prod(sh[1:]))
+                    v = (torch.rand(sh, generator=gen) * 2 - 1) / fan ** 0.5
+                store.p[k].copy_(v)
+        t.set_pool(ps, pp, normalize=(args.act == "tanh"))
+        return t
+
     ops = HipOps(dev)
     timed = RecordingOps(ops)
-    tr = FusedTrainer(timed, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
-                      seed=1234, process_group=pg, rank=rank, world=world)
-    from pgan_engine import disc_param_shapes, gen_param_shapes
-    gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
-    for store, shapes in ((tr.eng.G, gen_param_shapes()), (tr.eng.D, disc_param_shapes())):
-        for k, sh in shapes.items():
-            if len(sh) == 1:
-                v = torch.ones(sh) if k.endswith("weight") and not k.startswith("out") else torch.zeros(sh)
-            else:
-                fan = int(np.prod(sh[1:]))
-                v = (torch.rand(sh, generator=gen) * 2 - 1) / fan ** 0.5
-            store.p[k].copy_(v)
-    ps, pp = synthetic_pool(4096, 20260 + 1 + rank)
-    tr.set_pool(ps, pp, normalize=(args.act == "tanh"))
+    tr = make_trainer(timed)
 
     use_graph = (world == 1) and not args.no_graph
     step = tr.iteration
@@ -288,6 +294,24 @@ def main():
                    step_frac_of_fp32_mfma_peak=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
                    roofline=roofline)
+        if world == 1 and x3 and not args.no_fp32_pipe:
+            # the same step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
+            t32 = make_trainer(HipOps(dev, precision="fp32"))
+            n32 = max(5, args.steps // 2)
+            if use_graph:
+                t32.capture()
+            step32 = t32.replay if use_graph else t32.iteration
+            for _ in range(3):
+                step32()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n32):
+                step32()
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t1
+            out["fp32_pipe_only"] = dict(value=round(args.critic_iter * args.batch * n32 / d32, 2), unit="alignments/sec",
+                                         ms_per_step=round(d32 / n32 * 1e3, 4), steps=n32,
+                                         note="PGAN_CONV_PRECISION=fp32: all convolutions on the fp32 matrix pipe")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)
         print(json.dumps(out))
