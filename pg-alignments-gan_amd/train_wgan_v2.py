@@ -269,6 +269,35 @@ def save_models(trainer, gen_path, disc_path):
     torch.save(d, disc_path)
 
 
+def evaluate_2dswd(trainer, real_sites, normalize, n=500, seed=None):
+    """2DSWD of n generated against n input alignments (src/train_wgan_v2.py:686-693,723): one generator
+    forward over all n (BatchNorm in training mode, running statistics updated, as in the reference),
+    undo --normalize, genotype with sample_genotypes_bernoulli, SFS -> PCA(2) -> sliced Wasserstein.
+    Of the reference's --plot outputs only this number (w_dist_pca.txt) is produced."""
+    import numpy as np
+    from data_processing_v2 import plot_sfs_pca
+    from pgan_engine import Engine
+    eng = trainer.eng
+    n = min(n, real_sites.shape[0])
+    ev = getattr(trainer, "_eval_engine", None)
+    if ev is None or ev.B != n:
+        ev = Engine(trainer.ops, n, trainer.dev, loss=eng.loss, act=eng.act, latent=eng.latent,
+                    g_store=eng.G, g_buffers=eng.Gbuf, d_store=eng.D)
+        trainer._eval_engine = ev
+    z = torch.randn(n, eng.latent, device=trainer.dev)
+    fs = torch.empty(n, 1, 64, 64, device=trainer.dev)
+    fp = torch.empty(n, 1, 64, device=trainer.dev)
+    ev.gen_forward(z, fs, fp)
+    eng.g_batches_tracked += 1
+    if normalize:
+        fs = fs / 2 + 0.5
+    geno = sample_genotypes_bernoulli(fs.clamp(0, 1)).cpu().numpy()
+    pick = np.random.choice(range(real_sites.shape[0]), n, replace=False)
+    real = real_sites[pick]
+    real = real.cpu().numpy() if hasattr(real, "cpu") else np.asarray(real)
+    return plot_sfs_pca(geno, 0, real, 64, seed=seed)
+
+
 def main(argv=None):
     args = parse_args(argv)
     if not args.use_cuda or not torch.cuda.is_available():
@@ -302,6 +331,7 @@ def main(argv=None):
     d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
     trainer.eng.G.load({k: v for k, v in g0.state_dict().items() if k in trainer.eng.G.p})
     trainer.eng.D.load(d0.state_dict())
+    trainer.weights_changed()
     trainer.set_pool(sites, pos, normalize=normalize)
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
@@ -320,6 +350,11 @@ def main(argv=None):
         if save_freq != 0 and (epoch == 1 or epoch % save_freq == 0 or epoch == epochs):
             save_models(trainer, os.path.join(args.odir, "generator_model_{0:04d}.pt".format(epoch)),
                         os.path.join(args.odir, "discriminator_model_{0:04d}.pt".format(epoch)))
+            if args.plot:
+                w = evaluate_2dswd(trainer, sites, normalize)
+                logging.info("Epoch:\t%d 2DSWD: %6.8f" % (epoch, w))
+                with open(os.path.join(args.odir, "w_dist_pca.txt"), "a") as f:   # src/train_wgan_v2.py:724-726
+                    f.write(str(epoch) + "\t" + str(w) + "\n")
 
 
 if __name__ == "__main__":

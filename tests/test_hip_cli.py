@@ -38,3 +38,21 @@ def test_train_cli(tmp_path, extra):
     import layers
     G = layers.DC_Generator_Leaky_Sig(64, 128, 0.1, 1, 4)
     G.load_state_dict(g)            # interchangeable with the module front-end (and the reference's)
+
+
+def test_train_cli_writes_2dswd(tmp_path):
+    """--plot: the 2DSWD evaluation runs at every saved epoch and is appended to w_dist_pca.txt
+    (src/train_wgan_v2.py:723-726); its generator forward counts as a BatchNorm batch, as in the reference."""
+    import train_wgan_v2 as tw
+    idir, odir = tmp_path / "sims", tmp_path / "out"
+    idir.mkdir()
+    _write_sims(str(idir), 96)
+    tw.main(["--idir", str(idir), "--odir", str(odir), "--use_cuda", "--num_in", "96", "--batch_size", "8",
+             "--epochs", "2", "--save_freq", "1", "--critic_iter", "5", "--plot"])
+    lines = (odir / "w_dist_pca.txt").read_text().strip().splitlines()
+    assert [ln.split("\t")[0] for ln in lines] == ["1", "2"]
+    vals = [float(ln.split("\t")[1]) for ln in lines]
+    assert all(np.isfinite(v) and v > 0 for v in vals)
+    g = torch.load(odir / "generator_model_0002.pt", weights_only=True)
+    iters = 2 * ((96 // 8) // 5)
+    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 1     # saved before epoch 2's evaluation
