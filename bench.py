@@ -166,9 +166,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("PGAN_FORCE_DIST"):     # PGAN_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     from pgan_hip import HipOps
@@ -196,7 +198,7 @@ def main():
     timed = RecordingOps(ops)
     tr = make_trainer(timed)
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and pg is None and not args.no_graph
     step = tr.iteration
     if use_graph:
         tr.capture()
@@ -315,7 +317,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)
         print(json.dumps(out))
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

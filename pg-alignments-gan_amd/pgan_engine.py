@@ -188,7 +188,14 @@ class Engine:
         f = dict(dtype=torch.float32, device=device)
 
         # parameter stores may be handed in (the nn.Module front-ends own theirs) or created here
-        self.D = d_store if d_store is not None else FlatStore(disc_param_shapes(), device)
+        if d_store is None:
+            # the last 2-D stage's weights (3/4 of the discriminator) sit at the end of the flat buffers: their
+            # gradient is complete first in a backward pass and is reduced on its own in data-parallel runs,
+            # the rest then being one contiguous range
+            shapes = disc_param_shapes()
+            shapes["twod_conv_layers.9.weight"] = shapes.pop("twod_conv_layers.9.weight")
+            d_store = FlatStore(shapes, device)
+        self.D = d_store
         self.G = g_store if g_store is not None else FlatStore(gen_param_shapes(latent), device)
         if g_buffers is not None:
             self.Gbuf = g_buffers
@@ -201,6 +208,9 @@ class Engine:
         self.side = SideStream(device)
         self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
         self.gside = SideStream(device)     # generator forwards made one critic step ahead (FusedTrainer)
+        # called with a parameter name right after that discriminator weight gradient has been enqueued (on
+        # the stream it was enqueued on): lets a data-parallel driver start reducing it during the backward
+        self.grad_ready = None
 
         NT = self.NT
         # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
@@ -534,6 +544,8 @@ class Engine:
             self.wside.fork()
             with self.wside:
                 o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
+                if self.grad_ready is not None:
+                    self.grad_ready(f"twod_conv_layers.{3 * (k - 1)}.weight")
             if k > 1:
                 o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT])
                 hbar = self.dU[k - 1][NS:NT]

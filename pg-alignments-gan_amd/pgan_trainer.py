@@ -27,6 +27,14 @@ class FusedTrainer:
         self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g)
         self.eng.use_device_step_counters()
         self.rank, self.world, self.pg = rank, world, process_group
+        # data parallel: gradients are summed over the ranks before every Adam step.  The critic's largest
+        # gradient (the last 2-D stage's weights, 8.4 of 11.1 MB) is complete first in the backward pass and
+        # its reduction is started right then, beside the rest of the backward; the remainder follows.
+        self.dist_active = world > 1 or process_group is not None
+        self._early = []                      # (name, pending reduction)
+        self.early_names = ("twod_conv_layers.9.weight",)
+        if self.dist_active:
+            self.eng.grad_ready = self._early_reduce
         # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks differ in the seed's high word
         self.rng_z = torch.tensor([seed & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
         self.rng_t = torch.tensor([(seed + 1) & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
@@ -117,15 +125,37 @@ class FusedTrainer:
             self.iterations += 1
         elif self.graph is not None:
             self.replay()
-        elif self.use_graph and self.world == 1:
+        elif self.use_graph and not self.dist_active:
             self.capture()           # runs this iteration eagerly, then records the graph for the next ones
         else:
             self.iteration()
 
-    def _allreduce(self, flat: torch.Tensor) -> None:
-        if self.world > 1:
+    def _early_reduce(self, name: str) -> None:
+        if name in self.early_names:
             import torch.distributed as dist
+            work = dist.all_reduce(self.eng.D.g[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._early.append((name, work))
+
+    def _allreduce(self, flat: torch.Tensor) -> None:
+        """Sum `flat` (a store's whole gradient buffer) over the ranks and divide by their number; ranges whose
+        reduction was already started by _early_reduce are only waited for."""
+        if not self.dist_active:
+            return
+        import torch.distributed as dist
+        store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else None
+        if store is not None and self._early:
+            done = sorted((store.offsets[n], store.offsets[n] + store.p[n].numel()) for n, _ in self._early)
+            lo = 0
+            for a, b in done + [(flat.numel(), flat.numel())]:
+                if a > lo:
+                    dist.all_reduce(flat[lo:a], op=dist.ReduceOp.SUM, group=self.pg)
+                lo = b
+            for _, work in self._early:
+                work.wait()
+            self._early = []
+        else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world > 1:
             self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
     def _iteration_body(self) -> None:
@@ -172,7 +202,7 @@ class FusedTrainer:
     def capture(self) -> None:
         """Run ONE iteration eagerly (it counts as a training iteration and warms every kernel on the
         capture stream), then record the same launches into a hipGraph for replay()."""
-        if self.world > 1:
+        if self.dist_active:
             raise RuntimeError("graph capture is used on the single-GPU path only")
         torch.cuda.synchronize()
         if hasattr(self.ops, "invalidate_weight_planes"):
