@@ -132,17 +132,29 @@ __device__ __forceinline__ void gn_lrelu_bwd(float* g, const float* a, const flo
     __syncthreads();
 }
 
-// conv1d backward: d = d loss / d out [CO][LO]; in = conv input [CI][LO+3].
+// conv1d backward: d = d loss / d out [CO][LO]; in = conv input [CI][LO+3]; w = the layer's weights
+// [CO][CI][4] (in LDS).  Weight gradient: one thread per (co, ci) pair keeps the four taps' sums and slides a
+// window over `in`, two LDS reads per four multiply-adds.
 template <int CI, int CO, int LO>
-__device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, const float* __restrict__ w, float* pw,
+__device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, const float* w, float* pw,
                                            float* pbias, float* din) {
     constexpr int LI = LO + 3;
     if (pw) {
-        for (int idx = threadIdx.x; idx < CO * CI * 4; idx += blockDim.x) {
-            const int co = idx / (CI * 4), ci = (idx / 4) % CI, k = idx % 4;
-            float s = 0.f;
-            for (int l = 0; l < LO; ++l) s = fmaf(d[co * LO + l], in[ci * LI + l + k], s);
-            pw[idx] = s;
+        for (int pr = threadIdx.x; pr < CO * CI; pr += blockDim.x) {
+            const int co = pr / CI, ci = pr % CI;
+            const float* dp = d + co * LO;
+            const float* ip = in + ci * LI;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            float x0 = ip[0], x1 = ip[1], x2 = ip[2];
+            for (int l = 0; l < LO; ++l) {
+                const float x3 = ip[l + 3], dv = dp[l];
+                s0 = fmaf(dv, x0, s0);
+                s1 = fmaf(dv, x1, s1);
+                s2 = fmaf(dv, x2, s2);
+                s3 = fmaf(dv, x3, s3);
+                x0 = x1; x1 = x2; x2 = x3;
+            }
+            *reinterpret_cast<f32x4*>(pw + pr * 4) = f32x4{s0, s1, s2, s3};
         }
         for (int co = threadIdx.x; co < CO; co += blockDim.x) {
             float s = 0.f;
@@ -155,12 +167,12 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
             const int ci = idx / LI, li = idx % LI;
             float s = 0.f;
             for (int co = 0; co < CO; ++co) {
-                const float* wp = w + (co * CI + ci) * 4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int l = li - k;
-                    if (l >= 0 && l < LO) s = fmaf(d[co * LO + l], wp[k], s);
-                }
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (co * CI + ci) * 4);
+                const float* dp = d + co * LO + li;
+                if (li < LO) s = fmaf(dp[0], wv[0], s);
+                if (li >= 1 && li - 1 < LO) s = fmaf(dp[-1], wv[1], s);
+                if (li >= 2 && li - 2 < LO) s = fmaf(dp[-2], wv[2], s);
+                if (li >= 3) s = fmaf(dp[-3], wv[3], s);
             }
             din[idx] = s;
         }
@@ -175,8 +187,12 @@ __global__ __launch_bounds__(512) void d1d_bwd_kernel(const float* __restrict__ 
     __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], h1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], h2[D1_C2 * D1_L2],
         a3[D1_C3 * D1_L3], g3[D1_C3 * D1_L3], g2[D1_C2 * D1_L2], g1[D1_C1 * D1_L1], g0[D1_L0];
+    __shared__ __attribute__((aligned(16))) float w1s[D1_C1 * D1_C0 * 4], w2s[D1_C2 * D1_C1 * 4], w3s[D1_C3 * D1_C2 * 4];
     const int n = blockIdx.x, tid = threadIdx.x;
     float* prow = part ? part + (int64_t)n * part_ld : nullptr;
+    for (int i = tid; i < D1_C1 * D1_C0 * 4; i += blockDim.x) w1s[i] = P.cw[0][i];
+    for (int i = tid; i < D1_C2 * D1_C1 * 4; i += blockDim.x) w2s[i] = P.cw[1][i];
+    for (int i = tid; i < D1_C3 * D1_C2 * 4; i += blockDim.x) w3s[i] = P.cw[2][i];
     for (int i = tid; i < D1_L0; i += blockDim.x) x0[i] = xp[(int64_t)n * D1_L0 + i];
     for (int i = tid; i < D1_C1 * D1_L1; i += blockDim.x) a1[i] = a1s[(int64_t)n * D1_C1 * D1_L1 + i];
     for (int i = tid; i < D1_C2 * D1_L2; i += blockDim.x) a2[i] = a2s[(int64_t)n * D1_C2 * D1_L2 + i];
@@ -201,15 +217,15 @@ __global__ __launch_bounds__(512) void d1d_bwd_kernel(const float* __restrict__ 
     __syncthreads();
     gn_lrelu_bwd<D1_C3, D1_L3>(g3, a3, P.gw[2], P.gb[2], mu3, r3, sh, prow ? prow + off.o[10] : nullptr,
                                prow ? prow + off.o[11] : nullptr);
-    conv1d_bwd<D1_C2, D1_C3, D1_L3>(g3, h2, P.cw[2], prow ? prow + off.o[8] : nullptr, prow ? prow + off.o[9] : nullptr, g2);
+    conv1d_bwd<D1_C2, D1_C3, D1_L3>(g3, h2, w3s, prow ? prow + off.o[8] : nullptr, prow ? prow + off.o[9] : nullptr, g2);
     __syncthreads();
     gn_lrelu_bwd<D1_C2, D1_L2>(g2, a2, P.gw[1], P.gb[1], mu2, r2, sh, prow ? prow + off.o[6] : nullptr,
                                prow ? prow + off.o[7] : nullptr);
-    conv1d_bwd<D1_C1, D1_C2, D1_L2>(g2, h1, P.cw[1], prow ? prow + off.o[4] : nullptr, prow ? prow + off.o[5] : nullptr, g1);
+    conv1d_bwd<D1_C1, D1_C2, D1_L2>(g2, h1, w2s, prow ? prow + off.o[4] : nullptr, prow ? prow + off.o[5] : nullptr, g1);
     __syncthreads();
     gn_lrelu_bwd<D1_C1, D1_L1>(g1, a1, P.gw[0], P.gb[0], mu1, r1, sh, prow ? prow + off.o[2] : nullptr,
                                prow ? prow + off.o[3] : nullptr);
-    conv1d_bwd<D1_C0, D1_C1, D1_L1>(g1, x0, P.cw[0], prow ? prow + off.o[0] : nullptr, prow ? prow + off.o[1] : nullptr,
+    conv1d_bwd<D1_C0, D1_C1, D1_L1>(g1, x0, w1s, prow ? prow + off.o[0] : nullptr, prow ? prow + off.o[1] : nullptr,
                                     dxp ? g0 : nullptr);
     __syncthreads();
     if (dxp)
