@@ -241,7 +241,8 @@ def main():
             f["calls"] += r["calls"]
         dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
         x3 = getattr(ops, "precision", "fp32") == "x3"
-        pipe = {k: ("bf16" if (x3 and k != "conv_wgrad") else "fp32") for k in fam}
+        wg3 = x3 and getattr(ops, "wgrad_x3", False)
+        pipe = {k: ("bf16" if (x3 and (k != "conv_wgrad" or wg3)) else "fp32") for k in fam}
         roofline = None
         if dom:
             f = fam[dom]
@@ -262,8 +263,7 @@ def main():
                     traffic_of = key
             except (OSError, ValueError):
                 pass
-            kname = {"conv_up": "conv_up_x3_kernel", "conv_down": "conv_down_x3_kernel"}.get(dom, dom + "_kernel") \
-                if pipe[dom] == "bf16" else dom + "_kernel"
+            kname = dom + "_x3_kernel" if pipe[dom] == "bf16" else dom + "_kernel"
             roofline = dict(bound="mfma", kernel=f"{kname} ({pipe[dom]} matrix pipe, implicit GEMM)",
                             achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             traffic=traffic, traffic_shape=traffic_of,
@@ -286,8 +286,8 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    arithmetic=("fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
-                               "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe, weight "
-                               "gradients on the fp32 matrix pipe" if x3 else "fp32 throughout (fp32 matrix pipe)"),
+                               "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe"
+                               if x3 else "fp32 throughout (fp32 matrix pipe)"),
                    config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
                                         f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
                                global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,

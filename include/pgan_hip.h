@@ -58,6 +58,10 @@ long long pgan_conv_x3_prep_bytes(int Cs, int Cl);
 int pgan_conv_x3_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
 int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
 int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st);
+/* weight gradient with both operands split in the kernel (same arguments and scratch contract as pgan_conv_wgrad) */
+long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs);
+int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+                       int hs, int n_keep, int n_swap, hipStream_t st);
 /* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant"; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
 

@@ -416,6 +416,250 @@ __global__ __launch_bounds__(256 * NC) void conv_up_x3_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// WGRAD: dW[cs][cl][kh][kw] = sum over (n, oh, ow) of S[n][cs][oh][ow] * L[r(n)][cl][2oh-1+kh][2ow-1+kw].
+// GEMM M = cs (64 per block), N = (cl, tap) (8 cl x 16 taps per block), K = pixels, 64 per chunk, split
+// over gridDim.y into partial slabs.  Both operands are activations: both are split while they are
+// staged into LDS (single buffer, the next chunk's global loads in flight during the MFMAs).
+// A MFMA K step is 16 consecutive pixels (8 per lane half), so the L side is stored as an im2col along the
+// K direction only: for HS >= 8, per channel four kw-planes P[kw][row][ow] = L[row][2ow-1+kw], whose eight
+// consecutive ow are 16 contiguous bytes; for HS = 4 (eight pixels = two rows) a full im2col [tap][pixel].
+// Plane strides (HS >= 8) and a swap of the two 16-byte pixel halves on odd kh (HS = 4) spread the 16
+// (kh, kw) lanes of a channel evenly over the banks.
+// ------------------------------------------------------------------------------------------------
+template <int HS>
+struct WgGeom {
+    static constexpr int PIXC = 64, BM = 64, CLB = 8;
+    using T = PixTile<HS, PIXC>;
+    static constexpr int SEG = T::SEG, R = T::R, WS = HS, HL = 2 * HS, WL = 2 * HS;
+    static constexpr int ARS = PIXC * 2 + 16;                        // bytes per A row
+    static constexpr int APL = BM * ARS;                             // bytes per A plane
+    // HS >= 8: kw planes
+    static constexpr int PRR = 2 * R + 2;                            // raw rows per chunk
+    static constexpr int SR = WS * 2;                                // bytes per plane row (WS bf16)
+    static constexpr int KWB = PRR * SR + ((PRR * SR / 16) % 2 == 0 && HS == 16 ? 16 : 0);
+    static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB;        // bytes per (segment,) channel
+    static constexpr int BPL = (HS == 4) ? SEG * CLB * CHB : CLB * CHB;
+    static constexpr int LDS_BYTES = 3 * APL + 3 * BPL;
+    // staging items of the L side
+    static constexpr int NIB = (HS == 4) ? SEG * CLB * 4 * 4 : CLB * PRR * (WS / 2);
+    static constexpr int NQB = (NIB + 255) / 256;
+};
+
+template <int HS>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restrict__ YA, const float* __restrict__ X,
+                                                            float* __restrict__ slab, int N, int Cs, int Cl, int n_keep,
+                                                            int n_swap, int chunks_per_block) {
+    using G = WgGeom<HS>;
+    using T = typename G::T;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, SEG = G::SEG, R = G::R, PIXC = G::PIXC, BM = G::BM, CLB = G::CLB;
+    constexpr int AV = BM * PIXC / 4 / 256;          // f32x4 of the S tile per thread (4)
+    constexpr int NQB = G::NQB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
+    unsigned char* As = lds;
+    unsigned char* Bs = lds + 3 * G::APL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int nct = Cl / CLB;
+    const int cs0 = (blockIdx.x / nct) * BM, cl0 = (blockIdx.x % nct) * CLB;
+    const int total_chunks = T::ntiles(N);
+    const int c_begin = blockIdx.y * chunks_per_block;
+    const int c_end = min(total_chunks, c_begin + chunks_per_block);
+
+    // S tile: item q = (row, 4 pixels)
+    int a_row[AV], a_seg[AV], a_in[AV], a_lds[AV];
+#pragma unroll
+    for (int q = 0; q < AV; ++q) {
+        const int idx = tid + 256 * q, row = idx / (PIXC / 4), p = (idx % (PIXC / 4)) * 4;
+        a_row[q] = row;
+        a_seg[q] = p / (R * WS);
+        a_in[q] = p % (R * WS);
+        a_lds[q] = row * G::ARS + p * 2;
+    }
+    f32x4 areg[AV];
+    // L side items
+    constexpr int NBR = (HS == 4) ? 8 : 6;            // raw floats per item
+    float breg[NQB][NBR];
+    auto gload = [&](int chunk) {
+        int n0, oh0;
+        T::origin(chunk, n0, oh0);
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            const int n = n0 + a_seg[q];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < N)
+                v = *reinterpret_cast<const f32x4*>(YA + (((int64_t)n * Cs + cs0 + a_row[q]) * HS + oh0) * WS + a_in[q]);
+            areg[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            const int e = tid + 256 * q;
+            if constexpr (HS == 4) {
+                const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
+                const int n = n0 + seg, ih = 2 * oh - 1 + kh;
+                const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
+                const bool ok = e < G::NIB && n < N && ih >= 0 && ih < HL;
+                const float* src = X + (((int64_t)(ok ? rn : 0) * Cl + cl0 + ch) * HL + (ok ? ih : 0)) * WL;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { breg[q][i] = ok ? v0[i] : 0.f; breg[q][4 + i] = ok ? v1[i] : 0.f; }
+            } else {
+                constexpr int ND = WS / 2;
+                const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
+                const int n = n0, ih = 2 * oh0 - 1 + r;
+                const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
+                const bool ok = e < G::NIB && n < N && ih >= 0 && ih < HL;
+                const float* src = X + (((int64_t)(ok ? rn : 0) * Cl + cl0 + ch) * HL + (ok ? ih : 0)) * WL + 4 * d;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                breg[q][0] = (ok && d > 0) ? src[-1] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) breg[q][1 + i] = ok ? v[i] : 0.f;
+                breg[q][5] = (ok && 4 * d + 4 < WL) ? src[4] : 0.f;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < AV; ++q) {
+            uint32_t pa[3], pb[3];
+            split3(areg[q][0], areg[q][1], pa);
+            split3(areg[q][2], areg[q][3], pb);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                u32x2 v = {pa[i], pb[i]};
+                *reinterpret_cast<u32x2*>(As + i * G::APL + a_lds[q]) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            const int e = tid + 256 * q;
+            if (e >= G::NIB) continue;
+            if constexpr (HS == 4) {
+                const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
+                uint32_t s01[3], s23[3], s45[3], s67[3];
+                split3(breg[q][0], breg[q][1], s01);
+                split3(breg[q][2], breg[q][3], s23);
+                split3(breg[q][4], breg[q][5], s45);
+                split3(breg[q][6], breg[q][7], s67);
+                unsigned char* base = Bs + ((seg * CLB + ch) * 16 + kh * 4) * 32 + (((oh >> 1) ^ (kh & 1)) * 2 + (oh & 1)) * 8;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // values at input columns 2ow-1+kw for ow = 0..3: kw 0: (-,1,3,5)  1: (0,2,4,6)  2: (1,3,5,7)  3: (2,4,6,-)
+                    const u32x2 k0 = {s01[i] & 0xffff0000u, (s23[i] >> 16) | (s45[i] & 0xffff0000u)};
+                    const u32x2 k1 = {(s01[i] & 0xffffu) | (s23[i] << 16), (s45[i] & 0xffffu) | (s67[i] << 16)};
+                    const u32x2 k2 = {(s01[i] >> 16) | (s23[i] & 0xffff0000u), (s45[i] >> 16) | (s67[i] & 0xffff0000u)};
+                    const u32x2 k3 = {(s23[i] & 0xffffu) | (s45[i] << 16), s67[i] & 0xffffu};
+                    unsigned char* b = base + i * G::BPL;
+                    *reinterpret_cast<u32x2*>(b) = k0;
+                    *reinterpret_cast<u32x2*>(b + 32) = k1;
+                    *reinterpret_cast<u32x2*>(b + 64) = k2;
+                    *reinterpret_cast<u32x2*>(b + 96) = k3;
+                }
+            } else {
+                constexpr int ND = WS / 2;
+                const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
+                uint32_t s01[3], s23[3], s45[3];
+                split3(breg[q][0], breg[q][1], s01);
+                split3(breg[q][2], breg[q][3], s23);
+                split3(breg[q][4], breg[q][5], s45);
+                unsigned char* base = Bs + ch * G::CHB + r * G::SR + d * 4;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // plane kw, positions (2d, 2d+1) = input columns (4d-1+kw, 4d+1+kw)
+                    unsigned char* b = base + i * G::BPL;
+                    *reinterpret_cast<uint32_t*>(b) = (s01[i] & 0xffffu) | (s23[i] << 16);
+                    *reinterpret_cast<uint32_t*>(b + G::KWB) = (s01[i] >> 16) | (s23[i] & 0xffff0000u);
+                    *reinterpret_cast<uint32_t*>(b + 2 * G::KWB) = (s23[i] & 0xffffu) | (s45[i] << 16);
+                    *reinterpret_cast<uint32_t*>(b + 3 * G::KWB) = (s23[i] >> 16) | (s45[i] & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    // fragment addresses (bytes): A row of this lane; B column (cl, kh, kw) of this lane per pixel tile
+    const int abase = (wm * 32 + j) * G::ARS + h * 16;
+    int bbase[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int cl_l = wn * 4 + tn * 2 + (j >> 4), kh = (j >> 2) & 3, kw = j & 3;
+        if constexpr (HS == 16) bbase[tn] = cl_l * G::CHB + kw * G::KWB + kh * G::SR + h * 16;
+        else if constexpr (HS == 8) bbase[tn] = cl_l * G::CHB + kw * G::KWB + (2 * h + kh) * G::SR;
+        else bbase[tn] = (cl_l * 16 + (j & 15)) * 32 + (h ^ (kh & 1)) * 16;
+    }
+    // byte advance of the B fragment per K step (16 pixels)
+    constexpr int BSTEP = (HS == 16) ? 2 * G::SR : (HS == 8 ? 4 * G::SR : CLB * G::CHB);
+    f32x16 acc[2], acl[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[tn][r] = 0.f; acl[tn][r] = 0.f; }
+
+    if (c_begin < c_end) gload(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        lstore();
+        __syncthreads();
+        if (ch + 1 < c_end) gload(ch + 1);
+#pragma unroll
+        for (int s = 0; s < PIXC / 16; ++s) {
+            u32x4 a[3], bo[2][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + i * G::APL + abase + s * 32);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * G::BPL + bbase[tn] + s * BSTEP);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) mfma_x3(a, bo[tn], acc[tn], acl[tn]);
+        }
+        __syncthreads();
+    }
+
+    float* out = slab + (int64_t)blockIdx.y * Cs * Cl * 16;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = cs0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int cl = cl0 + wn * 4 + tn * 2 + (j >> 4);
+            out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = acc[tn][r] + acl[tn][r];
+        }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len) {
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= len) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + z * len + i4 * 4);
+    *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
+}
+
+template <int HS>
+int wgrad_x3_splits(int N, int Cs, int Cl) {
+    const int tiles = (Cs / 64) * (Cl / 8);
+    const int chunks = PixTile<HS, 64>::ntiles(N);
+    int want = (512 + tiles - 1) / tiles;        // ~2 blocks per CU
+    if (want > chunks) want = chunks;
+    if (want < 1) want = 1;
+    const int cpb = (chunks + want - 1) / want;
+    return (chunks + cpb - 1) / cpb;
+}
+
+template <int HS>
+int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
+                 int n_keep, int n_swap, hipStream_t st) {
+    if (Cs % 64 || Cl % 8) return PGAN_EINVAL;
+    const int chunks = PixTile<HS, 64>::ntiles(N);
+    const int ns = wgrad_x3_splits<HS>(N, Cs, Cl);
+    const int cpb = (chunks + ns - 1) / ns;
+    const int64_t len = (int64_t)Cs * Cl * 16;
+    if (ns * len > ws_floats) return PGAN_EINVAL;
+    conv_wgrad_x3_kernel<HS><<<dim3((Cs / 64) * (Cl / 8), ns), 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb);
+    slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len);
+    return pgan_launch_status();
+}
+
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st) {
     if (Cs % BM || Cl % (2 * CLC * ks)) return PGAN_EINVAL;
@@ -521,6 +765,30 @@ int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs,
         case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st);
         case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st);
         case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st);
+        default: return PGAN_EINVAL;
+    }
+}
+
+// Scratch floats pgan_conv_wgrad_x3 needs for these dimensions.
+long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs) {
+    int ns = 1;
+    switch (hs) {
+        case 4: ns = wgrad_x3_splits<4>(N, Cs, Cl); break;
+        case 8: ns = wgrad_x3_splits<8>(N, Cs, Cl); break;
+        case 16: ns = wgrad_x3_splits<16>(N, Cs, Cl); break;
+        default: return -1;
+    }
+    return (long long)ns * Cs * Cl * 16;
+}
+
+// dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)] as pgan_conv_wgrad, with the six-product bf16 split of both operands.
+int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+                       int hs, int n_keep, int n_swap, hipStream_t st) {
+    if (N <= 0) return PGAN_EINVAL;
+    switch (hs) {
+        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
         default: return PGAN_EINVAL;
     }
 }

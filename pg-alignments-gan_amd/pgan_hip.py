@@ -39,6 +39,7 @@ _SIGS = {
     "pgan_conv_x3_prep": [P, P, I, I, P],
     "pgan_conv_down_x3": [P, P, P, I, I, I, I, P],
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
+    "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, I, I, I, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
@@ -68,13 +69,15 @@ _SIGS = {
     "pgan_gemm": [P, P, P, I, I, I, I, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
-                                "pgan_conv_x3_prep_bytes"])
+                                "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = c_int
 _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
+_lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
+_lib.pgan_conv_wgrad_x3_workspace_floats.restype = c_longlong
 _lib.pgan_conv_x3_prep_bytes.argtypes = [I, I]
 _lib.pgan_conv_x3_prep_bytes.restype = c_longlong
 for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option):
@@ -149,6 +152,7 @@ class HipOps:
         # invalidate_weight_planes() after every weight update (otherwise planes are rebuilt per call)
         self._planes = {}
         self.static_weights = False
+        self.wgrad_x3 = os.environ.get("PGAN_WGRAD_X3", "1") != "0"     # weight gradients on the bf16 pipe too
 
     def invalidate_weight_planes(self, within: Optional[torch.Tensor] = None):
         """Mark prepared weight copies stale: all of them, or those whose weights live inside `within`."""
@@ -202,6 +206,13 @@ class HipOps:
         if n_keep is None:
             n_keep = N
         assert tuple(dw.shape[:2]) == (Cs, Cl) and x.shape[0] >= N and x.shape[2] == 2 * hs
+        if self.precision == "x3" and self.wgrad_x3 and Cl > 1:
+            need = _lib.pgan_conv_wgrad_x3_workspace_floats(N, Cs, Cl, hs)
+            if need < 0 or need > self.ws.numel():
+                raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
+            _check(_lib.pgan_conv_wgrad_x3(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs,
+                                           n_keep, n_swap, _stream()), "pgan_conv_wgrad_x3")
+            return
         need = _lib.pgan_conv_wgrad_workspace_floats(N, Cs, Cl, hs)
         if need < 0 or need > self.ws.numel():
             raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")

@@ -158,14 +158,19 @@ def test_bf16_pipe_extremes(hip):
 
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS)
-@pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (12, 0, 6)])
-def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap):
+@pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (12, 0, 6), (33, 11, 11)])
+@pytest.mark.parametrize("pipe", ["fp32", "bf16"])
+def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
     rng = np.random.default_rng(3)
     ya, x = rnd(rng, N, Cs, hs, hs), rnd(rng, N, Cl, 2 * hs, 2 * hs)
     want = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
     REF.conv_wgrad(*d64(ya, x), want, keep, swap)
     got = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
-    hip.conv_wgrad(*gpu(ya, x), got, keep, swap)
+    hip.wgrad_x3 = pipe == "bf16"
+    try:
+        hip.conv_wgrad(*gpu(ya, x), got, keep, swap)
+    finally:
+        hip.wgrad_x3 = True
     close("conv_wgrad", got, want)
 
 

@@ -14,7 +14,7 @@ def timeit(fn, reps=30):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-for N in (64, 192):
+for N in (64, 192, 256):
     for Cs, Cl, hs in LAYERS:
         fl = 2.0 * N * Cs * Cl * 16 * hs * hs
         y = torch.randn(N, Cs, hs, hs, device=dev); x = torch.randn(N, Cl, 2*hs, 2*hs, device=dev)
@@ -76,6 +76,16 @@ for N in (64, 192):
                 us = timeit(lambda: ops.conv_up(y, w, xx))
                 print(f"up   N={N:3d} hs={hs:2d} x3 v={var} ks={ks}:     {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {err:.2e}")
             set_x3_option("up_variant", 0); set_x3_option("up_ks", 0)
+        if which in ("wg3",):
+            ref = None
+            for px in (False, True):
+                ops.precision = "x3"; ops.wgrad_x3 = px
+                ops.conv_wgrad(y, x, dw)
+                if ref is None:
+                    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, y.double(), stride=2, padding=1)
+                err = float((dw.double() - ref).norm() / ref.norm())
+                us = timeit(lambda: ops.conv_wgrad(y, x, dw))
+                print(f"wgrd N={N:3d} hs={hs:2d} {'bf16 pipe' if px else 'fp32 pipe'}: {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {err:.2e}")
         if which in ("all", "wgrad"):
             us = timeit(lambda: ops.conv_wgrad(y, x, dw))
             print(f"wgrd N={N:3d} hs={hs:2d}:        {us:8.1f} us {fl/us/1e6:7.1f} TF")
