@@ -71,22 +71,24 @@ int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const
 
 /* ---- GroupNorm(1,C) + LeakyReLU(0.1), per-sample statistics (src/layers.py:442-443 and the three
  * repeats below it).  a, h, u, d, t, hd, hbar, p: [N][C][HW]; stats*: [N][2]; pg, pb: rows of per-channel sums, row stride pld.
- * C <= 512, HW a power of two >= 16, C*HW % 4096 == 0. */
-int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C, int HW,
-                hipStream_t st);
+ * C <= 512, C % 8 == 0, HW a power of two >= 16.  ws: scratch of pgan_gn_workspace_bytes(N) bytes (per-slice partial
+ * sums; every op is a sums launch plus an apply launch over 8 slices per sample). */
+long long pgan_gn_workspace_bytes(int N);
+int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
+                long long ws_bytes, int N, int C, int HW, hipStream_t st);
 /* first-order backward (autograd through GroupNorm/LeakyReLU): d = dL/da from u = dL/dh;
  * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta. */
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
-                float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, int N, int C, int HW,
-                hipStream_t st);
+                float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, void* ws, long long ws_bytes,
+                int N, int C, int HW, hipStream_t st);
 /* tangent (JVP) of the same block: hd from the tangent t of a; stats_t = (mean t, mean xhat*t). */
 int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, int N, int C, int HW, hipStream_t st);
+                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st);
 /* second-order backward: the piece of autograd's double backward (create_graph=True at
  * src/layers.py:51-53,66-74) that belongs to this block.  hbar may be NULL (= 0). */
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
                  const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 int N, int C, int HW, hipStream_t st);
+                 void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st);
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.1), src/layers.py:93-110,119-135.  a, h: [B][C][HW],
  * HW % 4 == 0; stats: [2][C] = batch mean, rstd; running stats updated in place (unbiased variance). */

@@ -12,7 +12,6 @@
 
 namespace {
 
-constexpr int NT = 1024;  // threads per block for the per-sample kernels
 
 // Adds v into sh[c] after reducing it over the GL consecutive lanes that share channel c.
 template <int NV>
@@ -26,30 +25,75 @@ __device__ __forceinline__ void channel_accumulate(float (&v)[NV], float* const 
     }
 }
 
-__global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, float* __restrict__ h,
-                                                    float* __restrict__ stats, int M, int HW) {
-    __shared__ double sh[2 * NT / 64];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + (int64_t)n * M);
-    f32x4* h4 = reinterpret_cast<f32x4*>(h + (int64_t)n * M);
+// Every GroupNorm op is two launches over (sample, slice) blocks, SL slices per sample so that small batches
+// still fill the chip: a sums pass that leaves each slice's partial sums (fp64) in `ws`, and an apply pass
+// in which every block adds the SL partials of its sample in a fixed order (deterministic) and streams its
+// slice.  A slice is a whole number of channels, so per-channel gamma / beta sums belong to one block.
+constexpr int SL = 8;     // slices per sample
+constexpr int ST = 256;   // threads per block
+
+struct Slice {
+    int n, s, tid;
+    int64_t base;     // first element of the slice
+    int q;            // float4 units in the slice
+    int c0;           // first channel of the slice
+    __device__ Slice(int M, int C) {
+        n = blockIdx.x / SL; s = blockIdx.x % SL; tid = threadIdx.x;
+        base = (int64_t)n * M + (int64_t)s * (M / SL);
+        q = M / SL / 4;
+        c0 = s * (C / SL);
+    }
+};
+
+template <int NV>
+__device__ __forceinline__ void put_partials(double (&red)[NV], double* sh, double* ws, const Slice& sl) {
+    block_sum<NV>(red, sh);
+    if (sl.tid == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ws[((int64_t)sl.n * SL + sl.s) * NV + i] = red[i];
+    }
+}
+template <int NV>
+__device__ __forceinline__ void get_totals(double (&tot)[NV], const double* ws, int n) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = 0.0;
+        for (int s = 0; s < SL; ++s) t += ws[((int64_t)n * SL + s) * NV + i];
+        tot[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(ST) void gn_fwd_sums(const float* __restrict__ a, double* __restrict__ ws, int M, int C) {
+    __shared__ double sh[2 * ST / 64];
+    const Slice sl(M, C);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     float s = 0.f, ss = 0.f;
-    for (int i = tid; i < M / 4; i += NT) {
+    for (int i = sl.tid; i < sl.q; i += ST) {
         const f32x4 v = a4[i];
         s += (v[0] + v[1]) + (v[2] + v[3]);
         ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     double red[2] = {s, ss};
-    block_sum<2>(red, sh);
-    const double mu_d = red[0] / M;
-    const double var = fmax(red[1] / M - mu_d * mu_d, 0.0);
+    put_partials<2>(red, sh, ws, sl);
+}
+__global__ __launch_bounds__(ST) void gn_fwd_apply(const float* __restrict__ a, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ h,
+                                                   float* __restrict__ stats, const double* __restrict__ ws, int M,
+                                                   int HW, int C) {
+    const Slice sl(M, C);
+    double tot[2];
+    get_totals<2>(tot, ws, sl.n);
+    const double mu_d = tot[0] / M;
+    const double var = fmax(tot[1] / M - mu_d * mu_d, 0.0);
     const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
-    if (tid == 0) {
-        stats[2 * n] = mu;
-        stats[2 * n + 1] = r;
+    if (sl.s == 0 && sl.tid == 0) {
+        stats[2 * sl.n] = mu;
+        stats[2 * sl.n + 1] = r;
     }
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    f32x4* h4 = reinterpret_cast<f32x4*>(h + sl.base);
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const int c = sl.c0 + (i * 4) / HW;
         const float g = gamma[c], b = beta[c];
         const f32x4 v = a4[i];
         f32x4 o;
@@ -61,27 +105,25 @@ __global__ __launch_bounds__(NT) void gn_fwd_kernel(const float* __restrict__ a,
 
 // first-order backward: d = J (gamma m u); per-sample stats (mean w, mean w xh); per-sample
 // per-channel partial sums of the gamma / beta gradients.
-__global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u, const float* __restrict__ h,
-                                                    const float* __restrict__ a, const float* __restrict__ stats,
-                                                    const float* __restrict__ gamma, float* __restrict__ d,
-                                                    float* __restrict__ stats_b, float* __restrict__ pg,
-                                                    float* __restrict__ pb, int M, int HW, int C, int pld) {
-    __shared__ double sh[2 * NT / 64];
-    __shared__ float cg[512], cb[512];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int GL = min(64, HW / 4);
-    const int64_t base = (int64_t)n * M;
-    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
-    f32x4* d4 = reinterpret_cast<f32x4*>(d + base);
-    const float mu = stats[2 * n], r = stats[2 * n + 1];
-    for (int c = tid; c < C; c += NT) { cg[c] = 0.f; cb[c] = 0.f; }
+__global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, const float* __restrict__ h,
+                                                  const float* __restrict__ a, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, float* __restrict__ pg,
+                                                  float* __restrict__ pb, double* __restrict__ ws, int M, int HW, int C,
+                                                  int pld) {
+    __shared__ double sh[2 * ST / 64];
+    __shared__ float cg[64], cb[64];
+    const Slice sl(M, C);
+    const int GL = min(64, HW / 4), cps = C / SL;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    for (int c = sl.tid; c < cps; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
     __syncthreads();
     float sw = 0.f, swx = 0.f;
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
-        const float g = gamma[c];
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const int cl = (i * 4) / HW;
+        const float g = gamma[sl.c0 + cl];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
         float pe[2] = {0.f, 0.f};
 #pragma unroll
@@ -93,22 +135,35 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u,
             pe[1] += ee;
         }
         float* const dst[2] = {cg, cb};
-        channel_accumulate<2>(pe, dst, c, GL);
+        channel_accumulate<2>(pe, dst, cl, GL);
     }
     double red[2] = {sw, swx};
-    block_sum<2>(red, sh);   // also orders the LDS atomics before the reads below
-    const float mw = (float)(red[0] / M), mwx = (float)(red[1] / M);
-    if (tid == 0) {
-        stats_b[2 * n] = mw;
-        stats_b[2 * n + 1] = mwx;
+    put_partials<2>(red, sh, ws, sl);   // its barriers also order the LDS atomics before the reads below
+    for (int c = sl.tid; c < cps; c += ST) {
+        pg[(int64_t)sl.n * pld + sl.c0 + c] = cg[c];
+        pb[(int64_t)sl.n * pld + sl.c0 + c] = cb[c];
     }
-    for (int c = tid; c < C; c += NT) {
-        pg[(int64_t)n * pld + c] = cg[c];
-        pb[(int64_t)n * pld + c] = cb[c];
+}
+__global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, const float* __restrict__ h,
+                                                   const float* __restrict__ a, const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, float* __restrict__ d,
+                                                   float* __restrict__ stats_b, const double* __restrict__ ws, int M,
+                                                   int HW, int C) {
+    const Slice sl(M, C);
+    double tot[2];
+    get_totals<2>(tot, ws, sl.n);
+    const float mw = (float)(tot[0] / M), mwx = (float)(tot[1] / M);
+    if (sl.s == 0 && sl.tid == 0) {
+        stats_b[2 * sl.n] = mw;
+        stats_b[2 * sl.n + 1] = mwx;
     }
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
-        const float g = gamma[c];
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    f32x4* d4 = reinterpret_cast<f32x4*>(d + sl.base);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
         f32x4 o;
 #pragma unroll
@@ -121,20 +176,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(const float* __restrict__ u,
 }
 
 // tangent forward: hd = m gamma J t.  Primal state (h, a, stats) of sample n; stats_t = (mean t, mean xh t).
-__global__ __launch_bounds__(NT) void gn_jvp_kernel(const float* __restrict__ t, const float* __restrict__ h,
-                                                    const float* __restrict__ a, const float* __restrict__ stats,
-                                                    const float* __restrict__ gamma, float* __restrict__ hd,
-                                                    float* __restrict__ stats_t, int M, int HW) {
-    __shared__ double sh[2 * NT / 64];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int64_t base = (int64_t)n * M;
-    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
-    f32x4* o4 = reinterpret_cast<f32x4*>(hd + base);
-    const float mu = stats[2 * n], r = stats[2 * n + 1];
+__global__ __launch_bounds__(ST) void gn_jvp_sums(const float* __restrict__ t, const float* __restrict__ a,
+                                                  const float* __restrict__ stats, double* __restrict__ ws, int M, int C) {
+    __shared__ double sh[2 * ST / 64];
+    const Slice sl(M, C);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     float st = 0.f, sxt = 0.f;
-    for (int i = tid; i < M / 4; i += NT) {
+    for (int i = sl.tid; i < sl.q; i += ST) {
         const f32x4 tv = t4[i], av = a4[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -143,15 +193,28 @@ __global__ __launch_bounds__(NT) void gn_jvp_kernel(const float* __restrict__ t,
         }
     }
     double red[2] = {st, sxt};
-    block_sum<2>(red, sh);
-    const float tb = (float)(red[0] / M), c_ = (float)(red[1] / M);
-    if (tid == 0) {
-        stats_t[2 * n] = tb;
-        stats_t[2 * n + 1] = c_;
+    put_partials<2>(red, sh, ws, sl);
+}
+__global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, const float* __restrict__ h,
+                                                   const float* __restrict__ a, const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, float* __restrict__ hd,
+                                                   float* __restrict__ stats_t, const double* __restrict__ ws, int M,
+                                                   int HW, int C) {
+    const Slice sl(M, C);
+    double tot[2];
+    get_totals<2>(tot, ws, sl.n);
+    const float tb = (float)(tot[0] / M), c_ = (float)(tot[1] / M);
+    if (sl.s == 0 && sl.tid == 0) {
+        stats_t[2 * sl.n] = tb;
+        stats_t[2 * sl.n + 1] = c_;
     }
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
-        const float g = gamma[c];
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    f32x4* o4 = reinterpret_cast<f32x4*>(hd + sl.base);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 tv = t4[i], hv = h4[i], av = a4[i];
         f32x4 o;
 #pragma unroll
@@ -167,34 +230,30 @@ __global__ __launch_bounds__(NT) void gn_jvp_kernel(const float* __restrict__ t,
 //   w = gamma m u, q = gamma m hbar, Q = q - r (c w + mwx t)
 //   p = r [ Q - mean Q - xh (mean(Q xh) + mean(w xd)) ],  xd = r (t - tb - xh c)
 // plus per-channel partials  pg = sum m u xd + m hbar xh,  pb = sum m hbar.   hbar may be null (= 0).
-__global__ __launch_bounds__(NT) void gn_bwd2_kernel(const float* __restrict__ hbar, const float* __restrict__ u,
-                                                     const float* __restrict__ t, const float* __restrict__ h,
-                                                     const float* __restrict__ a, const float* __restrict__ stats,
-                                                     const float* __restrict__ stats_b, const float* __restrict__ stats_t,
-                                                     const float* __restrict__ gamma, float* __restrict__ p,
-                                                     float* __restrict__ pg, float* __restrict__ pb, int M, int HW, int C,
-                                                     int pld) {
-    __shared__ double sh[3 * NT / 64];
-    __shared__ float cg[512], cb[512];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int GL = min(64, HW / 4);
-    const int64_t base = (int64_t)n * M;
-    const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + base) : nullptr;
-    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + base);
-    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + base);
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + base);
-    f32x4* p4 = reinterpret_cast<f32x4*>(p + base);
-    const float mu = stats[2 * n], r = stats[2 * n + 1];
-    const float mw = stats_b[2 * n], mwx = stats_b[2 * n + 1];
-    const float tb = stats_t[2 * n], c_ = stats_t[2 * n + 1];
+__global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hbar, const float* __restrict__ u,
+                                                   const float* __restrict__ t, const float* __restrict__ h,
+                                                   const float* __restrict__ a, const float* __restrict__ stats,
+                                                   const float* __restrict__ stats_t, const float* __restrict__ gamma,
+                                                   float* __restrict__ pg, float* __restrict__ pb,
+                                                   double* __restrict__ ws, int M, int HW, int C, int pld) {
+    __shared__ double sh[3 * ST / 64];
+    __shared__ float cg[64], cb[64];
+    const Slice sl(M, C);
+    const int GL = min(64, HW / 4), cps = C / SL;
+    const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    const float tb = stats_t[2 * sl.n], c_ = stats_t[2 * sl.n + 1];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int c = tid; c < C; c += NT) { cg[c] = 0.f; cb[c] = 0.f; }
+    for (int c = sl.tid; c < cps; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
     __syncthreads();
     float sq = 0.f, sqx = 0.f, swt = 0.f;
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
-        const float g = gamma[c];
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const int cl = (i * 4) / HW;
+        const float g = gamma[sl.c0 + cl];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
         float pe[2] = {0.f, 0.f};
 #pragma unroll
@@ -209,22 +268,41 @@ __global__ __launch_bounds__(NT) void gn_bwd2_kernel(const float* __restrict__ h
             pe[1] += m * bv[e];
         }
         float* const dst[2] = {cg, cb};
-        channel_accumulate<2>(pe, dst, c, GL);
+        channel_accumulate<2>(pe, dst, cl, GL);
     }
     double red[3] = {sq, sqx, swt};
-    block_sum<3>(red, sh);
-    const float mq = (float)(red[0] / M), mqx = (float)(red[1] / M), mwt = (float)(red[2] / M);
+    put_partials<3>(red, sh, ws, sl);
+    for (int c = sl.tid; c < cps; c += ST) {
+        pg[(int64_t)sl.n * pld + sl.c0 + c] = cg[c];
+        pb[(int64_t)sl.n * pld + sl.c0 + c] = cb[c];
+    }
+}
+__global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hbar, const float* __restrict__ u,
+                                                    const float* __restrict__ t, const float* __restrict__ h,
+                                                    const float* __restrict__ a, const float* __restrict__ stats,
+                                                    const float* __restrict__ stats_b, const float* __restrict__ stats_t,
+                                                    const float* __restrict__ gamma, float* __restrict__ p,
+                                                    const double* __restrict__ ws, int M, int HW, int C) {
+    const Slice sl(M, C);
+    double tot[3];
+    get_totals<3>(tot, ws, sl.n);
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    const float mw = stats_b[2 * sl.n], mwx = stats_b[2 * sl.n + 1];
+    const float tb = stats_t[2 * sl.n], c_ = stats_t[2 * sl.n + 1];
+    const float mq = (float)(tot[0] / M), mqx = (float)(tot[1] / M), mwt = (float)(tot[2] / M);
     const float mQ = mq - r * (c_ * mw + mwx * tb);
     const float mQx = mqx - 2.f * r * c_ * mwx;
     const float mwxd = r * (mwt - mw * tb - mwx * c_);
     const float kx = mQx + mwxd;
-    for (int c = tid; c < C; c += NT) {
-        pg[(int64_t)n * pld + c] = cg[c];
-        pb[(int64_t)n * pld + c] = cb[c];
-    }
-    for (int i = tid; i < M / 4; i += NT) {
-        const int c = (i * 4) / HW;
-        const float g = gamma[c];
+    const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
+    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    f32x4* p4 = reinterpret_cast<f32x4*>(p + sl.base);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = sl.tid; i < sl.q; i += ST) {
+        const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
         f32x4 o;
 #pragma unroll
@@ -327,41 +405,54 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
     }
 }
 
-bool gn_shape_ok(int N, int C, int HW) {
-    return N > 0 && C > 0 && C <= 512 && HW >= 16 && (HW & (HW - 1)) == 0 && (C * HW) % (4 * NT) == 0;
+bool gn_shape_ok(int N, int C, int HW, const void* ws, long long ws_bytes) {
+    return N > 0 && C > 0 && C <= 512 && C % SL == 0 && HW >= 16 && (HW & (HW - 1)) == 0 && (C * HW) % (4 * SL) == 0 &&
+           ws != nullptr && ws_bytes >= (long long)N * SL * 3 * 8;
 }
 
 }  // namespace
 
 extern "C" {
 
+// Scratch bytes the GroupNorm entry points need for N samples (slice partial sums).
+long long pgan_gn_workspace_bytes(int N) { return (long long)N * SL * 3 * 8; }
+
 // h = lrelu(GroupNorm(1,C)(a)); stats[n] = (mean, rstd).  a, h: [N, C, HW].
-int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C, int HW,
-                hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
-    gn_fwd_kernel<<<N, NT, 0, st>>>(a, gamma, beta, h, stats, C * HW, HW);
+int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
+                long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
+    double* w = static_cast<double*>(ws);
+    gn_fwd_sums<<<N * SL, ST, 0, st>>>(a, w, C * HW, C);
+    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C);
     return pgan_launch_status();
 }
 
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
-                float* stats_b, float* pg, float* pb, int pld, int N, int C, int HW, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW) || pld < C) return PGAN_EINVAL;
-    gn_bwd_kernel<<<N, NT, 0, st>>>(u, h, a, stats, gamma, d, stats_b, pg, pb, C * HW, HW, C, pld);
+                float* stats_b, float* pg, float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW,
+                hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
+    double* w = static_cast<double*>(ws);
+    gn_bwd_sums<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, pg, pb, w, C * HW, HW, C, pld);
+    gn_bwd_apply<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, d, stats_b, w, C * HW, HW, C);
     return pgan_launch_status();
 }
 
 int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, int N, int C, int HW, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW)) return PGAN_EINVAL;
-    gn_jvp_kernel<<<N, NT, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, C * HW, HW);
+                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
+    double* w = static_cast<double*>(ws);
+    gn_jvp_sums<<<N * SL, ST, 0, st>>>(t, a, stats, w, C * HW, C);
+    gn_jvp_apply<<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, w, C * HW, HW, C);
     return pgan_launch_status();
 }
 
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
                  const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 int N, int C, int HW, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW) || pld < C) return PGAN_EINVAL;
-    gn_bwd2_kernel<<<N, NT, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, C * HW, HW, C, pld);
+                 void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
+    double* w = static_cast<double*>(ws);
+    gn_bwd2_sums<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, pg, pb, w, C * HW, HW, C, pld);
+    gn_bwd2_apply<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, w, C * HW, HW, C);
     return pgan_launch_status();
 }
 

@@ -41,11 +41,11 @@ _SIGS = {
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
     "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
-    "pgan_gn_fwd": [P, P, P, P, P, I, I, I, P],
-    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P],
+    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
-    "pgan_gn_jvp": [P, P, P, P, P, P, P, I, I, I, P],
-    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
     "pgan_bn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
     "pgan_bn_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
@@ -69,13 +69,16 @@ _SIGS = {
     "pgan_gemm": [P, P, P, I, I, I, I, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
-                                "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats"])
+                                "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
+                                "pgan_gn_workspace_bytes"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = c_int
 _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
+_lib.pgan_gn_workspace_bytes.argtypes = [I]
+_lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_x3_workspace_floats.restype = c_longlong
 _lib.pgan_conv_x3_prep_bytes.argtypes = [I, I]
@@ -142,6 +145,7 @@ class HipOps:
         self.ws_small = torch.empty(4096, dtype=torch.float32, device=self.device)
         self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
         self.max_samples = max_samples
+        self.ws_gn = torch.empty(_lib.pgan_gn_workspace_bytes(4 * max_samples), dtype=torch.uint8, device=self.device)
         self._keep = []   # host-side arrays that must outlive an enqueue call
         # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
         # (fp32 accuracy); "fp32": the fp32 matrix pipe.  PGAN_CONV_PRECISION overrides the default.
@@ -237,26 +241,30 @@ class HipOps:
         _check(_lib.pgan_rows_reduce_multi(pa, ld, oa, cc, n, r0, r1, r2, r3, _stream()), "pgan_rows_reduce_multi")
 
     # ---------------- GroupNorm family ----------------
+    def _gnws(self):
+        return self.ws_gn.data_ptr(), self.ws_gn.numel()
+
     def gn_fwd(self, a, gamma, beta, h, stats):
         N, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), N, C, _hw(a), _stream()),
-               "pgan_gn_fwd")
+        _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
+                                _stream()), "pgan_gn_fwd")
 
     def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b),
-                                _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), N, C, _hw(a), _stream()), "pgan_gn_bwd")
+                                _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a), _stream()),
+               "pgan_gn_bwd")
 
     def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
         N, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(hd), _ptr(stats_t), N, C,
-                                _hw(a), _stream()), "pgan_gn_jvp")
+        _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(hd), _ptr(stats_t),
+                                *self._gnws(), N, C, _hw(a), _stream()), "pgan_gn_jvp")
 
     def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
-                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), N, C,
-                                 _hw(a), _stream()), "pgan_gn_bwd2")
+                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
+                                 *self._gnws(), N, C, _hw(a), _stream()), "pgan_gn_bwd2")
 
     # ---------------- BatchNorm ----------------
     def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
