@@ -92,10 +92,13 @@ int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float*
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.1), src/layers.py:93-110,119-135.  a, h: [B][C][HW],
  * HW % 4 == 0; stats: [2][C] = batch mean, rstd; running stats updated in place (unbiased variance). */
+/* ws: scratch of pgan_bn_workspace_bytes(C) bytes (large layers run as a sums launch plus an apply launch over
+ * several blocks per channel). */
+long long pgan_bn_workspace_bytes(int C);
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
-                float* stats, int B, int C, int HW, float momentum, hipStream_t st);
+                float* stats, void* ws, long long ws_bytes, int B, int C, int HW, float momentum, hipStream_t st);
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st);
+                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st);
 
 /* ---- linear head nn.Linear(11712, 1) over cat(2-D features, 1-D features), src/layers.py:482,491-493 */
 int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float* b, float* score, int N, int K2, int K1,

@@ -405,6 +405,119 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
     }
 }
 
+// Sliced BatchNorm: SB blocks per channel, each over B / SB samples; same two-launch scheme as GroupNorm.
+__global__ __launch_bounds__(BT) void bn_fwd_sums(const float* __restrict__ a, double* __restrict__ ws, int B, int C,
+                                                  int HW, int SB) {
+    __shared__ double sh[2 * BT / 64];
+    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
+    const int q = HW / 4, bs = B / SB, total = bs * q;
+    float s = 0.f, ss = 0.f;
+    for (int i = tid; i < total; i += BT) {
+        const int b = sl * bs + i / q, p = i % q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + ((int64_t)b * C + c) * HW + p * 4);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    double red[2] = {s, ss};
+    block_sum<2>(red, sh);
+    if (tid == 0) { ws[(c * SB + sl) * 2] = red[0]; ws[(c * SB + sl) * 2 + 1] = red[1]; }
+}
+__global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                                   float* __restrict__ rvar, float* __restrict__ h,
+                                                   float* __restrict__ stats, const double* __restrict__ ws, int B, int C,
+                                                   int HW, float momentum, int SB) {
+    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
+    const double cnt = (double)B * HW;
+    const double mu_d = t0 / cnt;
+    const double var = fmax(t1 / cnt - mu_d * mu_d, 0.0);
+    const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
+    if (sl == 0 && tid == 0) {
+        stats[c] = mu;
+        stats[C + c] = r;
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma[c], bt = beta[c];
+    const int q = HW / 4, bs = B / SB, total = bs * q;
+    for (int i = tid; i < total; i += BT) {
+        const int b = sl * bs + i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
+        *reinterpret_cast<f32x4*>(h + off) = o;
+    }
+}
+__global__ __launch_bounds__(BT) void bn_bwd_sums(const float* __restrict__ dh, const float* __restrict__ h,
+                                                  const float* __restrict__ a, const float* __restrict__ stats,
+                                                  double* __restrict__ ws, int B, int C, int HW, int SB) {
+    __shared__ double sh[2 * BT / 64];
+    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
+    const int q = HW / 4, bs = B / SB, total = bs * q;
+    const float mu = stats[c], r = stats[C + c];
+    float sb = 0.f, sg = 0.f;
+    for (int i = tid; i < total; i += BT) {
+        const int b = sl * bs + i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + off);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + off);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dy = lrelu_mask(hv[e]) * dv[e];
+            sb += dy;
+            sg += dy * ((av[e] - mu) * r);
+        }
+    }
+    double red[2] = {sb, sg};
+    block_sum<2>(red, sh);
+    if (tid == 0) { ws[(c * SB + sl) * 2] = red[0]; ws[(c * SB + sl) * 2 + 1] = red[1]; }
+}
+__global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh, const float* __restrict__ h,
+                                                   const float* __restrict__ a, const float* __restrict__ stats,
+                                                   const float* __restrict__ gamma, float* __restrict__ da,
+                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                   const double* __restrict__ ws, int B, int C, int HW, int SB) {
+    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
+    const double cnt = (double)B * HW;
+    const float mb = (float)(t0 / cnt), mg = (float)(t1 / cnt);
+    if (sl == 0 && tid == 0) {
+        dbeta[c] = (float)t0;
+        dgamma[c] = (float)t1;
+    }
+    const float mu = stats[c], r = stats[C + c], g = gamma[c];
+    const int q = HW / 4, bs = B / SB, total = bs * q;
+    for (int i = tid; i < total; i += BT) {
+        const int b = sl * bs + i / q, p = i % q;
+        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + off);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + off);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dy = lrelu_mask(hv[e]) * dv[e], xh = (av[e] - mu) * r;
+            o[e] = g * r * (dy - mb - xh * mg);
+        }
+        *reinterpret_cast<f32x4*>(da + off) = o;
+    }
+}
+
+// slices per channel: enough blocks to fill the chip, a whole number of samples each, only for large layers
+int bn_slices(int B, int C, int HW) {
+    if ((long long)B * HW < 8192) return 1;
+    int sb = 1;
+    while (C * sb * 2 <= 1024 && B % (sb * 2) == 0 && sb < 16) sb *= 2;
+    return sb;
+}
+
 bool gn_shape_ok(int N, int C, int HW, const void* ws, long long ws_bytes) {
     return N > 0 && C > 0 && C <= 512 && C % SL == 0 && HW >= 16 && (HW & (HW - 1)) == 0 && (C * HW) % (4 * SL) == 0 &&
            ws != nullptr && ws_bytes >= (long long)N * SL * 3 * 8;
@@ -457,17 +570,36 @@ int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float*
 }
 
 // a, h: [B, C, HW] (HW multiple of 4); stats: [2, C] = (batch mean, rstd); running stats updated in place.
+// ws: scratch of pgan_bn_workspace_bytes(C) bytes.
+long long pgan_bn_workspace_bytes(int C) { return (long long)C * 16 * 2 * 8; }
+
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h, float* stats,
-                int B, int C, int HW, float momentum, hipStream_t st) {
+                void* ws, long long ws_bytes, int B, int C, int HW, float momentum, hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
-    bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum);
+    const int sb = bn_slices(B, C, HW);
+    if (sb == 1) {
+        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum);
+    } else {
+        if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
+        double* w = static_cast<double*>(ws);
+        bn_fwd_sums<<<C * sb, BT, 0, st>>>(a, w, B, C, HW, sb);
+        bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb);
+    }
     return pgan_launch_status();
 }
 
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                float* dgamma, float* dbeta, int B, int C, int HW, hipStream_t st) {
+                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
-    bn_bwd_kernel<<<C, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, B, C, HW);
+    const int sb = bn_slices(B, C, HW);
+    if (sb == 1) {
+        bn_bwd_kernel<<<C, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, B, C, HW);
+    } else {
+        if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
+        double* w = static_cast<double*>(ws);
+        bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, w, B, C, HW, sb);
+        bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, w, B, C, HW, sb);
+    }
     return pgan_launch_status();
 }
 

@@ -46,8 +46,8 @@ _SIGS = {
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
     "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P],
     "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
-    "pgan_bn_fwd": [P, P, P, P, P, P, P, I, I, I, F, P],
-    "pgan_bn_bwd": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, P],
+    "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
     "pgan_head_seed": [P, P, P, I, I, P],
     "pgan_head_wgrad": [P, P, P, I, I, P],
@@ -70,13 +70,15 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
-                                "pgan_gn_workspace_bytes"])
+                                "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
     _fn.restype = c_int
 _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
+_lib.pgan_bn_workspace_bytes.argtypes = [I]
+_lib.pgan_bn_workspace_bytes.restype = c_longlong
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
@@ -145,6 +147,7 @@ class HipOps:
         self.ws_small = torch.empty(4096, dtype=torch.float32, device=self.device)
         self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
         self.max_samples = max_samples
+        self.ws_bn = torch.empty(_lib.pgan_bn_workspace_bytes(512), dtype=torch.uint8, device=self.device)
         self.ws_gn = torch.empty(_lib.pgan_gn_workspace_bytes(4 * max_samples), dtype=torch.uint8, device=self.device)
         self._keep = []   # host-side arrays that must outlive an enqueue call
         # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
@@ -269,13 +272,15 @@ class HipOps:
     # ---------------- BatchNorm ----------------
     def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
         B, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats), B, C,
-                                _hw(a), momentum, _stream()), "pgan_bn_fwd")
+        _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
+                                self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), momentum, _stream()),
+               "pgan_bn_fwd")
 
     def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
         B, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_bn_bwd(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
-                                _ptr(dbeta), B, C, _hw(a), _stream()), "pgan_bn_bwd")
+                                _ptr(dbeta), self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), _stream()),
+               "pgan_bn_bwd")
 
     # ---------------- head ----------------
     def head_fwd(self, h4, f1, w, b, score):

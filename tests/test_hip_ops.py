@@ -276,7 +276,7 @@ def test_rows_reduce_multi(hip):
     close("rows_reduce_multi2", outs[1], wants[1][1])
 
 
-@pytest.mark.parametrize("shape", [(6, 512, 4, 4), (6, 64, 32, 32), (6, 64, 4), (6, 8, 32)])
+@pytest.mark.parametrize("shape", [(6, 512, 4, 4), (6, 64, 32, 32), (6, 64, 4), (6, 8, 32), (16, 64, 32, 32), (24, 128, 16, 16)])
 def test_batchnorm(hip, shape):
     rng = np.random.default_rng(6)
     C = shape[1]
