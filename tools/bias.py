@@ -1,6 +1,6 @@
 """Does the bf16-pipe accumulation round or truncate?  All-positive operands expose a bias."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pg-alignments-gan_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pg-alignments-gan_amd"))
 import torch
 from pgan_hip import HipOps
 dev = torch.device("cuda:0"); ops = HipOps(dev)

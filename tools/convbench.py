@@ -1,6 +1,6 @@
 """Micro-benchmark of the conv kernel variants (tuning aid; run on the GPU box)."""
 import sys, os, itertools
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pg-alignments-gan_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pg-alignments-gan_amd"))
 import torch
 from pgan_hip import HipOps, set_option
 dev = torch.device("cuda:0")

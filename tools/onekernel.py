@@ -1,6 +1,6 @@
 """Launch one conv kernel shape a few times (for rocprofv3 --pmc passes)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pg-alignments-gan_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pg-alignments-gan_amd"))
 import torch
 from pgan_hip import HipOps, set_option
 kind, N, hs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
