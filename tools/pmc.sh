@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <kind> <N> <hs> [opts]   -- two PMC passes for one kernel shape
+# usage: tools/pmc.sh <tag> <kind> <N> <hs> [opts]   -- two PMC passes for one kernel shape
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_a -- python3 $GRAFT_REPO_ROOT/tools/onekernel.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/${tag}_a.log 2>&1 || exit 1
