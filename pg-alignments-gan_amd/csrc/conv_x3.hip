@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
 // between the MFMAs of chunk k while chunk k+2 is in flight from global memory into a second register set.
 // ------------------------------------------------------------------------------------------------
 template <int HS, int BM, int BN, int CLC>
-__global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
+__global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_down_x3_kernel(const float* __restri
 // Tap kh feeds output-row phase PH[kh] from S row a + DH[kh]:  kh 0:(1,+1) 1:(0,0) 2:(1,0) 3:(0,-1).
 // ------------------------------------------------------------------------------------------------
 template <int HS, int BN, int NC>
-__global__ __launch_bounds__(256 * NC) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
+__global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
