@@ -256,11 +256,12 @@ def main():
             traffic, traffic_of = None, None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                big = max((k for k in summ if k[0] == dom), key=lambda k: summ[k]["flops"])
-                key = f"{big[0]}[N={big[1]},Cs={big[2]},Cl={big[3]},hs={big[4]}]"
-                if key in pm:
-                    traffic = (pm[key]["FETCH_SIZE_KB"] + pm[key]["WRITE_SIZE_KB"]) * 1024
-                    traffic_of = key
+                name = lambda k: f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]"
+                have = [k for k in summ if k[0] == dom and name(k) in pm]
+                if have:       # the measured shape with the largest time share
+                    big = max(have, key=lambda k: summ[k]["total_ms"])
+                    traffic = (pm[name(big)]["FETCH_SIZE_KB"] + pm[name(big)]["WRITE_SIZE_KB"]) * 1024
+                    traffic_of = name(big)
             except (OSError, ValueError):
                 pass
             kname = dom + "_x3_kernel" if pipe[dom] == "bf16" else dom + "_kernel"

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
 // ------------------------------------------------------------------------------------------------
 template <int HS, int BN, int NC>
 __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
-                                                              float* __restrict__ X, int N, int Cs, int Cl) {
+                                                              float* __restrict__ X, int N, int Cs, int Cl,
+                                                              int cl_major) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -296,7 +297,11 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
     const int nmt = Cl / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
-    const int ptile = b / nmt, cl0 = (b % nmt) * BM + wc * 32;
+    // Each XCD gets a contiguous run of b.  cl_major: a run is one row tile (its weights stay in that XCD's L2)
+    // over all pixel tiles -- for layers whose weight planes outweigh the activations; otherwise a run is a
+    // range of pixel tiles over all row tiles.
+    const int ptile = cl_major ? b % npt : b / nmt;
+    const int cl0 = (cl_major ? b / npt : b % nmt) * BM + wc * 32;
     int n0, oh0;
     T::origin(ptile, n0, oh0);
 
@@ -669,6 +674,7 @@ int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs
 }
 
 int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0, g_up_ks = 0;   // tuning overrides (0 = by size)
+int g_up_order = 0;                                                 // 1: pixel-major, 2: row-tile-major block order
 
 template <int HS>
 int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st) {
@@ -709,12 +715,13 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     while (ks > 1 && Cs % (32 * ks)) ks >>= 1;
     if (ks > 1 && hipMemsetAsync(X, 0, sizeof(float) * (size_t)N * Cl * HS * HS * 4, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g(blocks, ks);
+    const int clm = g_up_order ? g_up_order - 1 : ((int64_t)Cs * Cl * 96 > (int64_t)N * Cs * HS * HS * 4);
     switch (variant) {
-        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
-        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
-        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
-        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl); break;
-        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl); break;
+        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
+        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
+        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
+        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
+        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
         default: return PGAN_EINVAL;
     }
     return pgan_launch_status();
@@ -730,6 +737,7 @@ int pgan_x3_set_option(const char* name, int value) {
     if (eq(name, "down_variant") && value >= 0 && value <= 4) { g_dn_variant = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
     if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
+    if (eq(name, "up_order") && value >= 0 && value <= 2) { g_up_order = value; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
