@@ -79,7 +79,7 @@ class RecordingOps:
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
-        if name not in self.NAMES:
+        if name not in self.NAMES or not callable(fn):
             return fn
 
         def wrapped(*a, **k):
@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "tanh"])
     ap.add_argument("--critic-iter", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--local-bn", action="store_true",
+                    help="several GPUs: BatchNorm statistics per GPU instead of over the global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=20, help="back-to-back launches per shape for per-kernel timing")
     ap.add_argument("--no-fp32-pipe", action="store_true", help="skip the side measurement with every convolution on the fp32 matrix pipe")
@@ -166,12 +168,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     pg = None
-    if world > 1 or os.environ.get("PGAN_FORCE_DIST"):     # PGAN_FORCE_DIST: exercise the RCCL path on one GPU
-        import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        pg = dist.group.WORLD
+    use_dist = world > 1 or bool(os.environ.get("PGAN_FORCE_DIST"))   # PGAN_FORCE_DIST: exercise the RCCL path on one GPU
 
     from pgan_hip import HipOps
     from pgan_trainer import FusedTrainer
@@ -181,7 +178,7 @@ def main():
 
     def make_trainer(backend):
         t = FusedTrainer(backend, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
-                         seed=1234, process_group=pg, rank=rank, world=world)
+                         seed=1234, rank=rank, world=world)
         gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
         for store, shapes in ((t.eng.G, gen_param_shapes()), (t.eng.D, disc_param_shapes())):
             for k, sh in shapes.items():
@@ -197,6 +194,14 @@ def main():
     ops = HipOps(dev)
     timed = RecordingOps(ops)
     tr = make_trainer(timed)
+    if use_dist:
+        # after the trainer: its four streams hold the process's four hardware queues, RCCL's streams share them
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        pg = dist.group.WORLD
+        tr.attach_process_group(pg, sync_bn=not args.local_bn)
 
     use_graph = (world == 1) and pg is None and not args.no_graph
     step = tr.iteration
@@ -292,7 +297,9 @@ def main():
                    config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
                                         f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
                                global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,
-                               hip_graph=bool(use_graph), parallelism=f"dp{world}"),
+                               hip_graph=bool(use_graph), parallelism=f"dp{world}",
+                               batchnorm=("global batch statistics (per-channel sums all-reduced)" if tr.sync_bn
+                                          else "per-GPU batch statistics")),
                    step_tflops=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12, 3),
                    step_frac_of_fp32_mfma_peak=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),

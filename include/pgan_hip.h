@@ -99,6 +99,19 @@ int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rm
                 float* stats, void* ws, long long ws_bytes, int B, int C, int HW, float momentum, hipStream_t st);
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
                 float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st);
+/* The same layers (src/layers.py:93-110,119-135) with batch statistics over the global batch of a data-parallel run
+ * (one process per GPU, B samples each): *_sums writes pgan_bn_partials(B, C, HW) doubles of per-channel partial sums
+ * (forward: sum a, sum a^2; backward: sum dy, sum dy xhat), the caller adds them over the ranks (all-reduce), *_apply
+ * finishes from the totals with world = number of ranks.  dgamma / dbeta are 1/world of the all-rank totals, so that
+ * the later sum of the parameter gradients over the ranks gives the totals. */
+long long pgan_bn_partials(int B, int C, int HW);
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, hipStream_t st);
+int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
+                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, hipStream_t st);
+int pgan_bn_bwd_sums(const float* dh, const float* h, const float* a, const float* stats, double* part, int B, int C,
+                     int HW, hipStream_t st);
+int pgan_bn_bwd_apply(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
+                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, hipStream_t st);
 
 /* ---- linear head nn.Linear(11712, 1) over cat(2-D features, 1-D features), src/layers.py:482,491-493 */
 int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float* b, float* score, int N, int K2, int K1,

@@ -426,11 +426,11 @@ __global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, 
                                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                                    float* __restrict__ rvar, float* __restrict__ h,
                                                    float* __restrict__ stats, const double* __restrict__ ws, int B, int C,
-                                                   int HW, float momentum, int SB) {
+                                                   int HW, float momentum, int SB, int world) {
     const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
     double t0 = 0.0, t1 = 0.0;
     for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
-    const double cnt = (double)B * HW;
+    const double cnt = (double)B * HW * world;   // world > 1: ws holds the partial sums added over all ranks
     const double mu_d = t0 / cnt;
     const double var = fmax(t1 / cnt - mu_d * mu_d, 0.0);
     const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
@@ -482,15 +482,16 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh,
                                                    const float* __restrict__ a, const float* __restrict__ stats,
                                                    const float* __restrict__ gamma, float* __restrict__ da,
                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                   const double* __restrict__ ws, int B, int C, int HW, int SB) {
+                                                   const double* __restrict__ ws, int B, int C, int HW, int SB,
+                                                   int world) {
     const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
     double t0 = 0.0, t1 = 0.0;
     for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
-    const double cnt = (double)B * HW;
+    const double cnt = (double)B * HW * world;
     const float mb = (float)(t0 / cnt), mg = (float)(t1 / cnt);
-    if (sl == 0 && tid == 0) {
-        dbeta[c] = (float)t0;
-        dgamma[c] = (float)t1;
+    if (sl == 0 && tid == 0) {   // every rank holds the all-rank totals: 1/world of them each, so that the ranks' sum is the total
+        dbeta[c] = (float)(t0 / world);
+        dgamma[c] = (float)(t1 / world);
     }
     const float mu = stats[c], r = stats[C + c], g = gamma[c];
     const int q = HW / 4, bs = B / SB, total = bs * q;
@@ -583,7 +584,7 @@ int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rm
         if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
         double* w = static_cast<double*>(ws);
         bn_fwd_sums<<<C * sb, BT, 0, st>>>(a, w, B, C, HW, sb);
-        bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb);
+        bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb, 1);
     }
     return pgan_launch_status();
 }
@@ -598,8 +599,44 @@ int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* st
         if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
         double* w = static_cast<double*>(ws);
         bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, w, B, C, HW, sb);
-        bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, w, B, C, HW, sb);
+        bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, w, B, C, HW, sb, 1);
     }
+    return pgan_launch_status();
+}
+
+// The same two passes as separate calls, for batch statistics over several GPUs: *_sums writes
+// pgan_bn_partials(B, C, HW) doubles of partial sums, the caller adds them over the ranks, *_apply (world = number of
+// ranks, each with B samples) finishes from the totals.  dgamma / dbeta come out as 1/world of the all-rank totals.
+long long pgan_bn_partials(int B, int C, int HW) { return (long long)C * bn_slices(B, C, HW) * 2; }
+
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C, HW);
+    bn_fwd_sums<<<C * sb, BT, 0, st>>>(a, part, B, C, HW, sb);
+    return pgan_launch_status();
+}
+
+int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
+                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C, HW);
+    bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, part, B, C, HW, momentum, sb, world);
+    return pgan_launch_status();
+}
+
+int pgan_bn_bwd_sums(const float* dh, const float* h, const float* a, const float* stats, double* part, int B, int C,
+                     int HW, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C, HW);
+    bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, part, B, C, HW, sb);
+    return pgan_launch_status();
+}
+
+int pgan_bn_bwd_apply(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
+                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C, HW);
+    bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, part, B, C, HW, sb, world);
     return pgan_launch_status();
 }
 

@@ -132,6 +132,8 @@ class SideStream:
     On the CPU backend every method is a no-op."""
 
     def __init__(self, device):
+        # Default priority on purpose: with streams of different priority classes the step deadlocked on the GPU (a
+        # higher-class hardware queue blocked on an event of a lower-class queue kept that queue from being served).
         self.enabled = torch.device(device).type == "cuda"
         if self.enabled:
             self.stream = torch.cuda.Stream(device=device)
@@ -205,6 +207,13 @@ class Engine:
                 if k.endswith("running_var"):
                     v.fill_(1.0)
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
+        # data parallel with batch statistics over all ranks' samples: bn_sync(partial sums, float64) adds them over
+        # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch
+        self.bn_sync = None
+        self.bn_world = 1
+        self._bn_parts = {}
+        # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
+        # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
         self.side = SideStream(device)
         self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
         self.gside = SideStream(device)     # generator forwards made one critic step ahead (FusedTrainer)
@@ -337,13 +346,43 @@ class Engine:
         self._gen_forward_1d(out_p)
         self._gen_forward_2d(out_s)
 
+    def _bn_part(self, key, a):
+        part = self._bn_parts.get(key)
+        if part is None:
+            hw = a.numel() // (a.shape[0] * a.shape[1])
+            part = torch.zeros(self.ops.bn_partials(a.shape[0], a.shape[1], hw), dtype=torch.float64, device=a.device)
+            self._bn_parts[key] = part
+        return part
+
+    def _bn_fwd(self, key, a, gamma, beta, rmean, rvar, h, stats) -> None:
+        """BatchNorm + LeakyReLU forward; with bn_sync set, over the global batch of all ranks (the partial sums of
+        every layer go through bn_sync, which adds them over the ranks on the current stream)."""
+        o = self.ops
+        if self.bn_sync is None:
+            o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats)
+            return
+        part = self._bn_part(("f", key), a)
+        o.bn_fwd_sums(a, part)
+        self.bn_sync(part)
+        o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world)
+
+    def _bn_bwd(self, key, dh, h, a, stats, gamma, da, dgamma, dbeta) -> None:
+        o = self.ops
+        if self.bn_sync is None:
+            o.bn_bwd(dh, h, a, stats, gamma, da, dgamma, dbeta)
+            return
+        part = self._bn_part(("b", key), a)
+        o.bn_bwd_sums(dh, h, a, stats, part)
+        self.bn_sync(part)
+        o.bn_bwd_apply(dh, h, a, stats, gamma, da, dgamma, dbeta, part, self.bn_world)
+
     def _gen_forward_2d(self, out_s: torch.Tensor) -> None:
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         o.gemm_nn(self.Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), self.gA[1].view(self.B, -1))
         for i in range(1, 5):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
-            o.bn_fwd(self.gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"], Gb[n + ".running_var"],
-                     self.gH[i], self.gStat[i])
+            self._bn_fwd(n, self.gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
+                         Gb[n + ".running_var"], self.gH[i], self.gStat[i])
             w = G[f"twod_conv_layers.{3 * i}.weight"]
             if i < 4:
                 o.conv_up(self.gH[i], w, self.gA[i + 1])
@@ -355,8 +394,8 @@ class Engine:
         o.gemm_nn(self.Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), self.hA[1].view(self.B, -1))
         for i in range(1, 5):
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
-            o.bn_fwd(self.hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"], Gb[n + ".running_var"],
-                     self.hH[i], self.hStat[i])
+            self._bn_fwd(n, self.hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
+                         Gb[n + ".running_var"], self.hH[i], self.hStat[i])
             w = G[f"oned_conv_layers.{3 * i}.weight"]
             if i < 4:
                 o.convt1d_up(self.hH[i], w, self.hA[i + 1])
@@ -381,8 +420,8 @@ class Engine:
             o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
             o.conv_down(up, w, self.gdH[i])
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
-            o.bn_bwd(self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
-                     dG[n + ".weight"], dG[n + ".bias"])
+            self._bn_bwd(n, self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
+                         dG[n + ".weight"], dG[n + ".bias"])
             up = self.gdA[i]
         o.gemm_tn(self.Z, self.gdA[1].view(self.B, -1), dG["twod_conv_layers.0.weight"].view(self.latent, -1))
 
@@ -395,8 +434,8 @@ class Engine:
             o.convt1d_wgrad(self.hH[i], up, dG[f"oned_conv_layers.{3 * i}.weight"])
             o.convt1d_down(up, w, self.hdH[i])
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
-            o.bn_bwd(self.hdH[i], self.hH[i], self.hA[i], self.hStat[i], G[n + ".weight"], self.hdA[i],
-                     dG[n + ".weight"], dG[n + ".bias"])
+            self._bn_bwd(n, self.hdH[i], self.hH[i], self.hA[i], self.hStat[i], G[n + ".weight"], self.hdA[i],
+                         dG[n + ".weight"], dG[n + ".bias"])
             up = self.hdA[i]
         o.gemm_tn(self.Z, self.hdA[1].view(self.B, -1), dG["oned_conv_layers.0.weight"].view(self.latent, -1))
 

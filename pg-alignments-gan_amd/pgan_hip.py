@@ -48,6 +48,10 @@ _SIGS = {
     "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
     "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, P],
     "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "pgan_bn_fwd_sums": [P, P, I, I, I, P],
+    "pgan_bn_fwd_apply": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "pgan_bn_bwd_sums": [P, P, P, P, P, I, I, I, P],
+    "pgan_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
     "pgan_head_seed": [P, P, P, I, I, P],
     "pgan_head_wgrad": [P, P, P, I, I, P],
@@ -70,7 +74,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
-                                "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes"])
+                                "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
@@ -79,6 +83,8 @@ _lib.pgan_conv_wgrad_workspace_floats.argtypes = [I, I, I, I]
 _lib.pgan_conv_wgrad_workspace_floats.restype = c_longlong
 _lib.pgan_bn_workspace_bytes.argtypes = [I]
 _lib.pgan_bn_workspace_bytes.restype = c_longlong
+_lib.pgan_bn_partials.argtypes = [I, I, I]
+_lib.pgan_bn_partials.restype = c_longlong
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
@@ -115,8 +121,16 @@ def _rows_ptr(t: torch.Tensor):
     return t.data_ptr()
 
 
+_DEVICE_INDEX = [0]                 # set by HipOps: one device per process
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Handle of torch's current stream on the op backend's device (every launch asks: the direct query is ~20x
+    cheaper than building a torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(_DEVICE_INDEX[0])
+    return torch.cuda.current_stream(_DEVICE_INDEX[0]).cuda_stream
 
 
 def _check(rc: int, what: str):
@@ -143,6 +157,7 @@ class HipOps:
         if not torch.cuda.is_available():
             raise PganError("HipOps needs a GPU")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _DEVICE_INDEX[0] = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.ws = torch.empty(ws_floats, dtype=torch.float32, device=self.device)
         self.ws_small = torch.empty(4096, dtype=torch.float32, device=self.device)
         self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
@@ -275,6 +290,39 @@ class HipOps:
         _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
                                 self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), momentum, _stream()),
                "pgan_bn_fwd")
+
+    # BatchNorm over the global batch of a data-parallel run: sums -> (caller adds `part` over the ranks) -> apply
+    def bn_partials(self, B, C, HW) -> int:
+        return int(_lib.pgan_bn_partials(B, C, HW))
+
+    @staticmethod
+    def _part_ptr(part, need):
+        if not part.is_cuda or part.dtype != torch.float64 or not part.is_contiguous() or part.numel() < need:
+            raise PganError("expected a contiguous float64 CUDA tensor of bn_partials() elements")
+        return part.data_ptr()
+
+    def bn_fwd_sums(self, a, part):
+        B, C = a.shape[:2]
+        _check(_lib.pgan_bn_fwd_sums(_ptr(a), self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), _stream()),
+               "pgan_bn_fwd_sums")
+
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1):
+        B, C = a.shape[:2]
+        _check(_lib.pgan_bn_fwd_apply(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
+                                      self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), int(world),
+                                      momentum, _stream()), "pgan_bn_fwd_apply")
+
+    def bn_bwd_sums(self, dh, h, a, stats, part):
+        B, C = a.shape[:2]
+        _check(_lib.pgan_bn_bwd_sums(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats),
+                                     self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), _stream()),
+               "pgan_bn_bwd_sums")
+
+    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world):
+        B, C = a.shape[:2]
+        _check(_lib.pgan_bn_bwd_apply(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
+                                      _ptr(dbeta), self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a),
+                                      int(world), _stream()), "pgan_bn_bwd_apply")
 
     def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
         B, C = a.shape[0], a.shape[1]

@@ -8,7 +8,9 @@ in device memory, and the losses stay in device buffers until the caller reads t
 
 Data parallel (one process per GPU, torch.distributed with the RCCL backend): every rank holds full
 replicas of both networks and optimiser states, draws its own batch / z / t, and the flat gradient
-buffers are all-reduced (mean) before each Adam step.  BatchNorm statistics stay per rank.
+buffers are all-reduced (mean) before each Adam step.  The generator's BatchNorm layers take their batch
+statistics over all ranks' samples (per-channel partial sums all-reduced inside forward and backward, the
+"global batch" of a single-device run) unless sync_bn=False keeps them per rank.
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ from pgan_engine import Engine
 class FusedTrainer:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  critic_iter: int = 5, seed: int = 1234, lr_d: float = 5e-5, lr_g: float = 5e-5,
-                 latent: int = 128, process_group=None, rank: int = 0, world: int = 1):
+                 latent: int = 128, process_group=None, rank: int = 0, world: int = 1, sync_bn: Optional[bool] = None):
         self.ops, self.dev, self.critic_iter = ops, device, int(critic_iter)
         self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g)
         self.eng.use_device_step_counters()
@@ -30,11 +32,11 @@ class FusedTrainer:
         # data parallel: gradients are summed over the ranks before every Adam step.  The critic's largest
         # gradient (the last 2-D stage's weights, 8.4 of 11.1 MB) is complete first in the backward pass and
         # its reduction is started right then, beside the rest of the backward; the remainder follows.
-        self.dist_active = world > 1 or process_group is not None
         self._early = []                      # (name, pending reduction)
         self.early_names = ("twod_conv_layers.9.weight",)
-        if self.dist_active:
-            self.eng.grad_ready = self._early_reduce
+        self.dist_active, self.sync_bn = False, False
+        if world > 1 or process_group is not None:
+            self.attach_process_group(process_group, sync_bn)
         # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks differ in the seed's high word
         self.rng_z = torch.tensor([seed & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
         self.rng_t = torch.tensor([(seed + 1) & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
@@ -48,6 +50,20 @@ class FusedTrainer:
         # anything else that writes parameters in place must call weights_changed()
         if hasattr(ops, "static_weights"):
             ops.static_weights = True
+
+    def attach_process_group(self, process_group=None, sync_bn: Optional[bool] = None) -> None:
+        """Switch on the data-parallel reductions over `process_group` (None: the default group once it exists).  A
+        trainer may be built before torch.distributed is initialised and attached afterwards: its streams then get
+        their hardware queues before the collective library creates streams of its own.
+        sync_bn: generator BatchNorm over the global batch (default; equals a single-device run at the global batch
+        size) or over each rank's own samples (False: no collectives inside the generator)."""
+        self.pg, self.dist_active = process_group, True
+        self.eng.grad_ready = self._early_reduce
+        self.sync_bn = True if sync_bn is None else bool(sync_bn)
+        if self.sync_bn:
+            self.eng.bn_sync, self.eng.bn_world = self._bn_allreduce, self.world
+        else:
+            self.eng.bn_sync, self.eng.bn_world = None, 1
 
     def weights_changed(self) -> None:
         """Tell the op backend that parameters were written outside the engine's optimizer steps."""
@@ -129,6 +145,10 @@ class FusedTrainer:
             self.capture()           # runs this iteration eagerly, then records the graph for the next ones
         else:
             self.iteration()
+
+    def _bn_allreduce(self, part: torch.Tensor) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _early_reduce(self, name: str) -> None:
         if name in self.early_names:

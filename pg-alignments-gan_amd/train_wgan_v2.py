@@ -235,9 +235,11 @@ def parse_args(argv=None):
     p.add_argument("--normalize", action="store_true", help="normalize inputs to [-1, 1] for tanh")
     p.add_argument("--shuffle_inds", action="store_true", help="shuffle individuals in each input alignment")
     p.add_argument("--verbose", action="store_true", help="verbose output to log")
+    p.add_argument("--local_bn", action="store_true",
+                   help="several GPUs: BatchNorm statistics of each GPU's own samples instead of the global batch")
     args = p.parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO)
-    if args.odir != "None":
+    if args.odir != "None" and int(os.environ.get("RANK", "0")) == 0:
         if not os.path.exists(args.odir):
             os.mkdir(args.odir)
         else:   # the reference empties an existing output directory (line 428)
@@ -312,11 +314,30 @@ def main(argv=None):
     normalize = args.normalize or args.gen == "tanNorm"
     if args.plot:
         logging.warning("--plot: the evaluation figures are not part of this package; continuing without them")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    # several GPUs (python -m torch.distributed.run --nproc-per-node N train_wgan_v2.py ...): --batch_size stays
+    # the global batch, split evenly; every rank reads the same files and trains on every world-th alignment
+    world, rank, pg = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), None
+    if world > 1:
+        import torch.distributed as dist
+        if batch % world:
+            raise SystemExit(f"--batch_size {batch} is not a multiple of the {world} GPUs")
+        backend = os.environ.get("PGAN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+        else:
+            dist.init_process_group(backend)
+        pg = dist.group.WORLD
+        batch //= world
 
+    if world > 1:
+        random.seed(1234)             # the ranks pick the same --num_in files
     data = DataGeneratorDisk(args.idir, num_in=num_in, batch_size=batch)
     sites, pos = data.load_all()
+    if world > 1:
+        random.seed()
     if args.mono_switch:
         sites, pos = switch_monomorphic(sites, pos, 0, 10)
     if args.label_smooth:
@@ -325,29 +346,37 @@ def main(argv=None):
         sites = sites * (1 - ey) + hi * ey
     trainer = FusedTrainer(HipOps(dev), batch, dev, loss=args.loss, act=act, lam=lam, critic_iter=critic_iter,
                            seed=random.randrange(1 << 30), lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
-                           latent=latent)
+                           latent=latent, process_group=pg, rank=rank, world=world,
+                           sync_bn=(not args.local_bn) if world > 1 else None)
     import layers   # default PyTorch initialisation of the reference's layer types
     g0 = (layers.DC_Generator_Leaky_Sig if act == "sigmoid" else layers.DC_Generator_Leaky_Tan)(64, latent, 0.1, 1, 4)
     d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
     trainer.eng.G.load({k: v for k, v in g0.state_dict().items() if k in trainer.eng.G.p})
     trainer.eng.D.load(d0.state_dict())
+    if world > 1:                      # rank 0's initial weights everywhere; disjoint shares of the input
+        import torch.distributed as dist
+        for flat in (trainer.eng.G.flat, trainer.eng.D.flat):
+            dist.broadcast(flat, src=0, group=pg)
+        pool_s, pool_p = sites[rank::world], pos[rank::world]
+    else:
+        pool_s, pool_p = sites, pos
     trainer.weights_changed()
-    trainer.set_pool(sites, pos, normalize=normalize)
+    trainer.set_pool(pool_s, pool_p, normalize=normalize)
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
     else:
         trainer.use_graph = True
 
-    iters_per_epoch = max(1, (num_in // batch) // critic_iter)
+    iters_per_epoch = max(1, (num_in // (batch * world)) // critic_iter)
     for epoch in range(1, epochs + 1):
         trainer.shuffle_pool(rows=args.permute or args.shuffle_inds)
         for j in range(iters_per_epoch):
             trainer.step()
-            if j % batch == 1:
+            if j % (batch * world) == 1 and rank == 0:
                 w, d_real, d_fake, pen, g_loss = trainer.losses()
                 logging.info("Epoch:\t%d/%d Discriminator loss: %6.8f Generator loss: %6.8f d_real: %6.8f d_fake: %6.8f"
                              % (epoch, epochs, w, g_loss, d_real, d_fake))
-        if save_freq != 0 and (epoch == 1 or epoch % save_freq == 0 or epoch == epochs):
+        if rank == 0 and save_freq != 0 and (epoch == 1 or epoch % save_freq == 0 or epoch == epochs):
             save_models(trainer, os.path.join(args.odir, "generator_model_{0:04d}.pt".format(epoch)),
                         os.path.join(args.odir, "discriminator_model_{0:04d}.pt".format(epoch)))
             if args.plot:
@@ -355,6 +384,15 @@ def main(argv=None):
                 logging.info("Epoch:\t%d 2DSWD: %6.8f" % (epoch, w))
                 with open(os.path.join(args.odir, "w_dist_pca.txt"), "a") as f:   # src/train_wgan_v2.py:724-726
                     f.write(str(epoch) + "\t" + str(w) + "\n")
+    if world > 1:
+        import torch.distributed as dist
+        dump = os.environ.get("PGAN_DUMP_WEIGHT_SUMS")      # test aid: the replicas must stay identical
+        if dump:
+            with open(os.path.join(dump, f"weights_rank{rank}.txt"), "w") as f:
+                f.write(repr([float(x.double().sum()) for x in (trainer.eng.G.flat, trainer.eng.D.flat)]) + "\n")
+                f.write(repr([float(v.double().sum()) for v in trainer.eng.Gbuf.p.values()]) + "\n")
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -44,6 +44,7 @@ def _worker(rank, world, port, loss, B, out_dir):
     dist.all_reduce(loss_part)
     if rank == 0:
         torch.save({"g": tr.eng.D.gflat.clone(), "loss": loss_part / world}, os.path.join(out_dir, "dp.pt"))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -63,3 +64,91 @@ def test_two_rank_gradients_equal_single_process(tmp_path, loss):
     err = float((got["g"] - eng.D.gflat).norm() / eng.D.gflat.norm())
     assert err < 2e-6, err
     assert torch.allclose(got["loss"], eng.closs, rtol=1e-5, atol=1e-6)
+
+
+def _gen_worker(rank, world, port, B, out_dir):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_trainer import FusedTrainer
+    from torch_ops import TorchOps
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = FusedTrainer(TorchOps(), B // world, torch.device("cpu"), process_group=dist.group.WORLD, rank=rank, world=world)
+    assert tr.sync_bn
+    tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    z = torch.from_numpy(np.random.Generator(np.random.PCG64(50)).standard_normal((B, 128, 1, 1))).float()
+    tr.eng.generator_grads(z[rank * B // world:(rank + 1) * B // world])
+    tr._allreduce(tr.eng.G.gflat)
+    loss_part = tr.eng.gloss.clone()
+    dist.all_reduce(loss_part)
+    if rank == 1:     # the other rank holds the same reduced gradients and running statistics
+        torch.save({"g": tr.eng.G.gflat.clone(), "loss": loss_part / world,
+                    "buf": {k: v.clone() for k, v in tr.eng.Gbuf.p.items()}}, os.path.join(out_dir, "dpg.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_generator_step_with_global_batch_statistics(tmp_path):
+    """BatchNorm couples the generator's samples (src/layers.py:93-108,119-134): with the per-channel sums reduced
+    over the ranks, two ranks of B/2 give the gradients, loss and running statistics of one process at B."""
+    from pgan_engine import Engine
+    from torch_ops import TorchOps
+    B = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gen_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "dpg.pt", weights_only=True)
+    eng = Engine(TorchOps(), B, torch.device("cpu"))
+    eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    z = torch.from_numpy(np.random.Generator(np.random.PCG64(50)).standard_normal((B, 128, 1, 1))).float()
+    eng.generator_grads(z)
+    err = float((got["g"] - eng.G.gflat).norm() / eng.G.gflat.norm())
+    assert err < 5e-6, err
+    assert torch.allclose(got["loss"].reshape(-1), eng.gloss.reshape(-1), rtol=1e-5, atol=1e-6)
+    for k, v in eng.Gbuf.p.items():
+        assert torch.allclose(got["buf"][k], v, rtol=1e-5, atol=1e-6), k
+
+
+def _iter_worker(rank, world, port, sync_bn, out_dir):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_trainer import FusedTrainer
+    from torch_ops import TorchOps
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = FusedTrainer(TorchOps(), 2, torch.device("cpu"), critic_iter=2, process_group=dist.group.WORLD, rank=rank,
+                      world=world, sync_bn=sync_bn)
+    tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    rs, rp = orc.synthetic_alignments(16, 70)
+    tr.set_pool(rs[rank::world], rp[rank::world])
+    for _ in range(2):
+        tr.step()
+    torch.save({"g": tr.eng.G.flat.clone(), "d": tr.eng.D.flat.clone(), "losses": tr.losses(),
+                "buf": {k: v.clone() for k, v in tr.eng.Gbuf.p.items()}}, os.path.join(out_dir, f"it{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_two_rank_iterations_keep_the_replicas_identical(tmp_path, sync_bn):
+    """Two full iterations of FusedTrainer on two ranks (each its own real batches, z and t; the early reduction of
+    the critic's largest gradient, generator forwards one step ahead, both Adam steps): the replicas' weights stay
+    bit-identical and move; with statistics over the global batch the BatchNorm running statistics agree too, with
+    per-rank statistics they differ."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_iter_worker, args=(2, port, sync_bn, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"it{r}.pt", weights_only=True) for r in (0, 1))
+    assert torch.equal(a["g"], b["g"]) and torch.equal(a["d"], b["d"])
+    assert all(np.isfinite(v) for v in a["losses"])
+    same = all(torch.equal(a["buf"][k], b["buf"][k]) for k in a["buf"])
+    assert same == sync_bn
+    d0 = torch.cat([v.reshape(-1) for v in orc.make_params(orc.disc_param_shapes(), 7).values()])
+    assert float(a["d"].abs().sum()) != float(d0.abs().sum())

@@ -56,3 +56,4 @@ def test_train_cli_writes_2dswd(tmp_path):
     g = torch.load(odir / "generator_model_0002.pt", weights_only=True)
     iters = 2 * ((96 // 8) // 5)
     assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 1     # saved before epoch 2's evaluation
+

@@ -1,0 +1,105 @@
+"""Data-parallel path on the GPU kernels: two processes share the one GPU of the test box (gloo moves the
+CUDA tensors, as RCCL does between GPUs), each with half of the batch.  Reduced gradients, losses and the
+generator's running statistics equal one process at the whole batch: the critic has no batch coupling, the
+generator's BatchNorm layers reduce their per-channel sums over the ranks (src/layers.py:93-108,119-134)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dcwgan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+B = 8
+
+
+def _inputs(seed):
+    rs, rp = orc.synthetic_alignments(B, seed)
+    g = np.random.Generator(np.random.PCG64(seed + 2))
+    t = torch.from_numpy(g.random((B, 1, 1, 1))).float()
+    z = torch.from_numpy(g.standard_normal((B, 128, 1, 1))).float()
+    return rs, rp, t, z
+
+
+def _run(tr, rs, rp, t, z, sl, dev):
+    """One critic step's gradients (fakes from this rank's z rows), then one generator step's; both reduced."""
+    e = tr.eng
+    e.critic_grads(rs[sl].to(dev), rp[sl].to(dev), z[sl].to(dev), t[sl].to(dev) if e.loss == "gp" else None)
+    tr._allreduce(e.D.gflat)
+    out = {"d": e.D.gflat.clone().cpu(), "closs": e.closs.clone().cpu()}
+    e.generator_grads(z[sl].flip(0).contiguous().to(dev))
+    tr._allreduce(e.G.gflat)
+    out.update(g=e.G.gflat.clone().cpu(), gloss=e.gloss.clone().cpu().reshape(-1),
+               buf={k: v.clone().cpu() for k, v in e.Gbuf.p.items()})
+    return out
+
+
+def _load(tr):
+    tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    tr.weights_changed()
+
+
+def _worker(rank, world, port, loss, out_dir):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tr = FusedTrainer(HipOps(dev), B // world, dev, loss=loss, process_group=dist.group.WORLD, rank=rank, world=world)
+    assert tr.sync_bn
+    _load(tr)
+    rs, rp, t, z = _inputs(60)
+    # rank r holds the global batch's rows [r B/2, (r+1) B/2); generator_grads sees them flipped within the rank
+    out = _run(tr, rs, rp, t, z, slice(rank * B // world, (rank + 1) * B // world), dev)
+    for k in ("closs", "gloss"):
+        v = out[k].to(dev)
+        dist.all_reduce(v)
+        out[k] = (v / world).cpu()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(out, os.path.join(out_dir, "dp.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss):
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, loss, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "dp.pt", weights_only=True)
+    dev = torch.device("cuda", 0)
+    tr = FusedTrainer(HipOps(dev), B, dev, loss=loss)
+    _load(tr)
+    rs, rp, t, z = _inputs(60)
+    e = tr.eng
+    e.critic_grads(rs.to(dev), rp.to(dev), z.to(dev), t.to(dev) if loss == "gp" else None)
+    want_d, want_closs = e.D.gflat.clone().cpu(), e.closs.clone().cpu()
+    zg = torch.cat([z[:B // 2].flip(0), z[B // 2:].flip(0)]).contiguous()
+    e.generator_grads(zg.to(dev))
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(got["d"], want_d) < 1e-5, rel(got["d"], want_d)
+    assert torch.allclose(got["closs"], want_closs, rtol=2e-5, atol=1e-6)
+    assert rel(got["g"], e.G.gflat.cpu()) < 1e-5, rel(got["g"], e.G.gflat.cpu())
+    assert torch.allclose(got["gloss"], e.gloss.cpu().reshape(-1), rtol=2e-5, atol=1e-6)
+    for k, v in e.Gbuf.p.items():
+        assert torch.allclose(got["buf"][k], v.cpu(), rtol=2e-5, atol=1e-6), k
+

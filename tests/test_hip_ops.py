@@ -302,6 +302,55 @@ def test_batchnorm(hip, shape):
     close("bn_bwd.dbeta", db_g, db_w)
 
 
+@pytest.mark.parametrize("shape", [(8, 512, 4, 4), (32, 64, 32, 32), (8, 64, 4), (16, 128, 16, 16)])
+def test_batchnorm_over_two_ranks(hip, shape):
+    """Split entry points: two "ranks" of B/2 samples whose partial sums are added equal one BatchNorm over B."""
+    rng = np.random.default_rng(16)
+    B, C = shape[:2]
+    a, dh = rnd(rng, *shape) * 0.5 + 0.2, rnd(rng, *shape)
+    gamma, beta = 1 + 0.2 * rnd(rng, C), 0.2 * rnd(rng, C)
+    rm, rv = 0.1 * rnd(rng, C), 1 + 0.1 * rnd(rng, C).abs()
+    h_w, st_w = torch.zeros(shape, dtype=torch.float64), torch.zeros(2, C, dtype=torch.float64)
+    rm_w, rv_w = rm.double().clone(), rv.double().clone()
+    REF.bn_fwd(*d64(a, gamma, beta), rm_w, rv_w, h_w, st_w)
+    halves = [slice(0, B // 2), slice(B // 2, B)]
+    ag, dhg = a.to(DEV), dh.to(DEV)
+    hw = int(np.prod(shape[2:]))
+    n = hip.bn_partials(B // 2, C, hw)
+    parts = [torch.zeros(n, dtype=torch.float64, device=DEV) for _ in halves]
+    for sl, part in zip(halves, parts):
+        hip.bn_fwd_sums(ag[sl], part)
+    total = parts[0] + parts[1]
+    h_g = torch.zeros(shape, device=DEV)
+    stats, run = [], []
+    for sl in halves:
+        st_g, rm_g, rv_g = torch.zeros(2, C, device=DEV), rm.to(DEV), rv.to(DEV)
+        hip.bn_fwd_apply(ag[sl], *gpu(gamma, beta), rm_g, rv_g, h_g[sl], st_g, total, 2)
+        stats.append(st_g)
+        run.append((rm_g, rv_g))
+    close("bn2.h", h_g, h_w)
+    for rm_g, rv_g in run:
+        close("bn2.rmean", rm_g, rm_w)
+        close("bn2.rvar", rv_g, rv_w)
+    assert torch.equal(stats[0], stats[1])
+    da_w = torch.zeros(shape, dtype=torch.float64)
+    dg_w, db_w = torch.zeros(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
+    REF.bn_bwd(*d64(dh, h_g.cpu(), a), st_w, gamma.double(), da_w, dg_w, db_w)
+    for sl, part in zip(halves, parts):
+        hip.bn_bwd_sums(dhg[sl], h_g[sl], ag[sl], stats[0], part)
+    total = parts[0] + parts[1]
+    da_g = torch.zeros(shape, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    for sl in halves:
+        dg_g, db_g = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        hip.bn_bwd_apply(dhg[sl], h_g[sl], ag[sl], stats[0], gamma.to(DEV), da_g[sl], dg_g, db_g, total, 2)
+        dg += dg_g
+        db += db_g
+    close("bn2.da", da_g, da_w)
+    close("bn2.dgamma", dg, dg_w)      # the ranks' values add up to the total
+    close("bn2.dbeta", db, db_w)
+
+
 def test_head_and_penalties(hip):
     rng = np.random.default_rng(7)
     N, K2, K1 = 6, 8192, 3520

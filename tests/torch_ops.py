@@ -211,6 +211,47 @@ class TorchOps:
         rmean.mul_(1 - momentum).add_(momentum * mu)
         rvar.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
 
+    # split form for batch statistics over several ranks: part[c] = (sum, sum of squares) resp. (sum dy, sum dy xhat)
+    def bn_partials(self, B, C, HW) -> int:
+        return 2 * C
+
+    def bn_fwd_sums(self, a, part):
+        red = (0,) + tuple(range(2, a.dim()))
+        ad = a.double()
+        part.view(-1, 2)[:, 0] = ad.sum(red)
+        part.view(-1, 2)[:, 1] = (ad * ad).sum(red)
+
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1):
+        sh = (1, -1) + (1,) * (a.dim() - 2)
+        n = world * a.numel() // a.shape[1]
+        mu = part.view(-1, 2)[:, 0] / n
+        var = (part.view(-1, 2)[:, 1] / n - mu * mu).clamp_min(0)
+        r = torch.rsqrt(var + EPS).float()
+        mu32 = mu.float()
+        h.copy_(F.leaky_relu(gamma.view(sh) * ((a - mu32.view(sh)) * r.view(sh)) + beta.view(sh), SLOPE))
+        stats[0] = mu32
+        stats[1] = r
+        rmean.mul_(1 - momentum).add_(momentum * mu32)
+        rvar.mul_(1 - momentum).add_(momentum * (var * (n / max(n - 1, 1))).float())
+
+    def bn_bwd_sums(self, dh, h, a, stats, part):
+        red = (0,) + tuple(range(2, a.dim()))
+        sh = (1, -1) + (1,) * (a.dim() - 2)
+        xh = (a - stats[0].view(sh)) * stats[1].view(sh)
+        dy = _mask(h) * dh
+        part.view(-1, 2)[:, 0] = dy.double().sum(red)
+        part.view(-1, 2)[:, 1] = (dy * xh).double().sum(red)
+
+    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world):
+        sh = (1, -1) + (1,) * (a.dim() - 2)
+        n = world * a.numel() // a.shape[1]
+        xh = (a - stats[0].view(sh)) * stats[1].view(sh)
+        dy = _mask(h) * dh
+        sb, sg = part.view(-1, 2)[:, 0], part.view(-1, 2)[:, 1]
+        dgamma.copy_((sg / world).float())
+        dbeta.copy_((sb / world).float())
+        da.copy_(gamma.view(sh) * stats[1].view(sh) * (dy - (sb / n).float().view(sh) - xh * (sg / n).float().view(sh)))
+
     def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
         red = (0,) + tuple(range(2, a.dim()))
         sh = (1, -1) + (1,) * (a.dim() - 2)
@@ -246,12 +287,30 @@ class TorchOps:
         dw.copy_(torch.nn.grad.conv1d_weight(x, dw.shape, ya, stride=2, padding=1))
 
     # ---------------- optimiser / misc ----------------
-    def adam(self, p, g, m, v, step, lr, b1, b2, eps):
+    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None):
+        if step_dev is not None:      # step count kept in a tensor: incremented, then used
+            step_dev += 1
+            step = int(step_dev)
         bc1 = 1.0 - b1 ** step
         bc2 = 1.0 - b2 ** step
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+    def philox(self, out, state, normal):
+        """Stand-in for the device generator (same interface, not the same numbers): values are a function of the
+        4-word state, whose offset words advance by the number of 4-value groups drawn."""
+        g = torch.Generator().manual_seed(int(state[0]) + 7919 * int(state[1]) + 104729 * int(state[2]))
+        v = torch.randn(out.shape, generator=g) if normal else torch.rand(out.shape, generator=g)
+        out.copy_(v)
+        state[2] += (out.numel() + 3) // 4
+
+    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor):
+        n, B = pool_s.shape[0], out_s.shape[0]
+        idx = (int(cursor) + torch.arange(B)) % n
+        out_s.copy_(pool_s[idx])
+        out_p.copy_(pool_p[idx])
+        cursor.copy_((cursor + B) % n)
 
     def affine(self, x, scale, shift, out):
         out.copy_(x * scale + shift)
