@@ -318,18 +318,10 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     # several GPUs (python -m torch.distributed.run --nproc-per-node N train_wgan_v2.py ...): --batch_size stays
     # the global batch, split evenly; every rank reads the same files and trains on every world-th alignment
-    world, rank, pg = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), None
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:
-        import torch.distributed as dist
         if batch % world:
             raise SystemExit(f"--batch_size {batch} is not a multiple of the {world} GPUs")
-        backend = os.environ.get("PGAN_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
-        else:
-            dist.init_process_group(backend)
-        pg = dist.group.WORLD
         batch //= world
 
     if world > 1:
@@ -346,8 +338,11 @@ def main(argv=None):
         sites = sites * (1 - ey) + hi * ey
     trainer = FusedTrainer(HipOps(dev), batch, dev, loss=args.loss, act=act, lam=lam, critic_iter=critic_iter,
                            seed=random.randrange(1 << 30), lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
-                           latent=latent, process_group=pg, rank=rank, world=world,
-                           sync_bn=(not args.local_bn) if world > 1 else None)
+                           latent=latent, rank=rank, world=world, sync_bn=(not args.local_bn) if world > 1 else None)
+    if world > 1:      # after the trainer, whose streams then hold the hardware queues ahead of the collective library's
+        import torch.distributed as dist
+        backend = os.environ.get("PGAN_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     import layers   # default PyTorch initialisation of the reference's layer types
     g0 = (layers.DC_Generator_Leaky_Sig if act == "sigmoid" else layers.DC_Generator_Leaky_Tan)(64, latent, 0.1, 1, 4)
     d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
@@ -356,7 +351,7 @@ def main(argv=None):
     if world > 1:                      # rank 0's initial weights everywhere; disjoint shares of the input
         import torch.distributed as dist
         for flat in (trainer.eng.G.flat, trainer.eng.D.flat):
-            dist.broadcast(flat, src=0, group=pg)
+            dist.broadcast(flat, src=0)
         pool_s, pool_p = sites[rank::world], pos[rank::world]
     else:
         pool_s, pool_p = sites, pos

@@ -1,5 +1,5 @@
 """Data-parallel path on the GPU kernels: two processes share the one GPU of the test box (gloo moves the
-CUDA tensors, as RCCL does between GPUs), each with half of the batch.  Reduced gradients, losses and the
+CUDA tensors, as RCCL does between GPUs), each with half of the batch.  (Collected after the other GPU tests.)  Reduced gradients, losses and the
 generator's running statistics equal one process at the whole batch: the critic has no batch coupling, the
 generator's BatchNorm layers reduce their per-channel sums over the ranks (src/layers.py:93-108,119-134)."""
 import os
@@ -57,6 +57,14 @@ def _worker(rank, world, port, loss, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    # gloo stages CUDA tensors through high-priority streams; a high-priority stream waiting for work of the
+    # default-priority compute streams can stall the GPU here, so every collective starts on an idle device
+    reduce_ = dist.all_reduce
+
+    def all_reduce_idle(*a, **k):
+        torch.cuda.synchronize()
+        return reduce_(*a, **k)
+    dist.all_reduce = all_reduce_idle
     tr = FusedTrainer(HipOps(dev), B // world, dev, loss=loss, process_group=dist.group.WORLD, rank=rank, world=world)
     assert tr.sync_bn
     _load(tr)
