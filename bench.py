@@ -154,7 +154,8 @@ def main():
     ap.add_argument("--loss", default="gp", choices=["gp", "div"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "tanh"])
     ap.add_argument("--critic-iter", type=int, default=5)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches only")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay even where eager launches are faster")
     ap.add_argument("--local-bn", action="store_true",
                     help="several GPUs: BatchNorm statistics per GPU instead of over the global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,9 +206,25 @@ def main():
 
     use_graph = (world == 1) and pg is None and not args.no_graph
     step = tr.iteration
+    route = "eager launches (several GPUs: no graph capture around RCCL)" if pg is not None else "eager launches (--no-graph)"
     if use_graph:
+        # one GPU: hipGraph replay or eager launches from the host, whichever is faster here (the same kernels on the
+        # same streams; the host enqueues an iteration in about 7 ms) -- decided on 10 untimed iterations of each
         tr.capture()
-        step = tr.replay
+
+        def rate(fn, n=10):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        t_graph, t_eager = rate(tr.replay), rate(tr.iteration)
+        use_graph = args.graph or t_graph <= t_eager
+        step = tr.replay if use_graph else tr.iteration
+        route = (f"{'hipGraph replay' if use_graph else 'eager launches'} (calibration: graph {t_graph * 1e3:.2f} ms, "
+                 f"eager {t_eager * 1e3:.2f} ms per iteration)")
     for _ in range(args.warmup):
         step()
 
@@ -297,7 +314,7 @@ def main():
                    config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
                                         f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
                                global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,
-                               hip_graph=bool(use_graph), parallelism=f"dp{world}",
+                               hip_graph=bool(use_graph), launch=route, parallelism=f"dp{world}",
                                batchnorm=("global batch statistics (per-channel sums all-reduced)" if tr.sync_bn
                                           else "per-GPU batch statistics")),
                    step_tflops=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12, 3),

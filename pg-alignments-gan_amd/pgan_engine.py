@@ -211,6 +211,8 @@ class Engine:
         # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch
         self.bn_sync = None
         self.bn_world = 1
+        import os
+        self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
         self._bn_parts = {}
         # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
         # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
@@ -546,21 +548,38 @@ class Engine:
             o.head_wgrad(self.ones2B, self.coef_w, Dg["out.bias"])
         if run_generator:
             self._gen_forward_2d(self.X0[B:2 * B])
-        if self.loss == "gp":
-            o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
-        # primal forward
-        self._d_forward2d(0, NS)
-        self.side.wait_mark()
-        o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
-        # first-order backward (+ input gradient of the penalised samples)
         self.coef_cur = self.coef
-        self._d_backward1(0, NS, NS - NP, NS, self.G0[:NP])
+        two_chains = self.loss == "gp" and self.two_chains
+        if two_chains:
+            # gp: the Wasserstein term (real | fake: forward + first-order backward) and the penalty term
+            # (interpolates: forward, backward, tangent forward, second backward) are independent chains of equal
+            # length; they run side by side, each one's convolutions beside the other's small kernels.  The
+            # Wasserstein chain goes first on the weight-gradient stream.
+            if hasattr(o, "prepare_weights"):
+                o.prepare_weights([self.dconv_w(k) for k in range(1, 5)])
+            self.wside.fork()
+            with self.wside:
+                self._d_forward2d(0, 2 * B)
+                self.side.wait_mark()
+                o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
+                self._d_backward1(0, 2 * B, 0, 0, None)
+            o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
+            self._d_forward2d(2 * B, NS)
+            self._d_backward1(2 * B, NS, NS - NP, NS, self.G0[:NP])
+        else:
+            if self.loss == "gp":
+                o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
+            # primal forward
+            self._d_forward2d(0, NS)
+            self.side.wait_mark()
+            o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
+            # first-order backward (+ input gradient of the penalised samples)
+            self._d_backward1(0, NS, NS - NP, NS, self.G0[:NP])
         # penalty value and v = d penalty / d g, written as the tangent input
         if self.loss == "gp":
             o.gp_penalty(self.G0[:NP], self.lam, self.X0[NS:NT], self.pen)
         else:
             o.div_penalty(self.G0[:NP], B, self.X0[NS:NT], self.pen)
-        o.critic_loss(self.score, B, self.pen, self.closs)
         # tangent forward of v through the 2-D tower (primal state = the penalised samples' slots)
         pl, ph = NS - NP, NS
         for k in range(1, 5):
@@ -589,6 +608,9 @@ class Engine:
                 o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT])
                 hbar = self.dU[k - 1][NS:NT]
         self.wside.join()
+        if two_chains and hasattr(o, "release_weights"):
+            o.release_weights()
+        o.critic_loss(self.score, B, self.pen, self.closs)
         r = (0, 2 * B, NS, NT) if self.loss == "gp" else (NS, NT, 0, 0)
         o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), *r)
         o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])

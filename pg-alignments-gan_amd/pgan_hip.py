@@ -164,6 +164,8 @@ class HipOps:
         self.max_samples = max_samples
         self.ws_bn = torch.empty(_lib.pgan_bn_workspace_bytes(512), dtype=torch.uint8, device=self.device)
         self.ws_gn = torch.empty(_lib.pgan_gn_workspace_bytes(4 * max_samples), dtype=torch.uint8, device=self.device)
+        self._ws_gn = {}
+        self._hold = False
         self._keep = []   # host-side arrays that must outlive an enqueue call
         # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
         # (fp32 accuracy); "fp32": the fp32 matrix pipe.  PGAN_CONV_PRECISION overrides the default.
@@ -196,7 +198,7 @@ class HipOps:
             nbytes = _lib.pgan_conv_x3_prep_bytes(Cs, Cl)
             ent = [torch.empty(nbytes, dtype=torch.uint8, device=self.device), False]
             self._planes[key] = ent
-        if not (ent[1] and self.static_weights):
+        if not (ent[1] and (self.static_weights or self._hold)):
             _check(_lib.pgan_conv_x3_prep(_ptr(w), ent[0].data_ptr(), Cs, Cl, _stream()), "pgan_conv_x3_prep")
             ent[1] = True
         return ent[0].data_ptr()
@@ -260,7 +262,27 @@ class HipOps:
 
     # ---------------- GroupNorm family ----------------
     def _gnws(self):
-        return self.ws_gn.data_ptr(), self.ws_gn.numel()
+        """Slice-sum scratch of the GroupNorm kernels, one per stream: chains of GroupNorm calls run concurrently on
+        different streams (the critic's two sample chains)."""
+        key = _stream()
+        ws = self._ws_gn.get(key)
+        if ws is None:
+            ws = self.ws_gn if not self._ws_gn else torch.empty_like(self.ws_gn)
+            self._ws_gn[key] = ws
+        return ws.data_ptr(), ws.numel()
+
+    def prepare_weights(self, weights) -> None:
+        """Build the prepared copies of these convolution weights now, on the current stream, so that later uses on
+        several streams (all ordered after this point) find them ready."""
+        if self.precision == "x3":
+            self._hold = False
+            for w in weights:
+                if w.shape[1] > 1:
+                    self._weight_planes(w)
+            self._hold = True         # until release_weights(): no re-preparation from a second stream
+
+    def release_weights(self) -> None:
+        self._hold = False
 
     def gn_fwd(self, a, gamma, beta, h, stats):
         N, C = a.shape[0], a.shape[1]
