@@ -173,6 +173,27 @@ int pgan_ct1d_wgrad(const float* ya, const float* x, float* dw, int N, int Cs, i
  * ConvTranspose layers on a 1x1 / length-1 input (src/layers.py:92,117) and their weight gradients. */
 int pgan_gemm(const float* A, const float* B, float* C, int M, int N, int K, int transa, hipStream_t st);
 
+/* ---- input pipeline: the reference's alignment files (`<n>_sites.csv`, 64 lines of 64 comma-separated 0/1,
+ * src/sim_conversion/convert_ms.py:39; `<n>_pos.csv`, 64 lines of one float, convert_ms.py:28-29) parsed natively into
+ * bit-packed form (replaces the two np.loadtxt calls per alignment of DataGeneratorDisk.get_batch,
+ * src/train_wgan_v2.py:254-255), and the device kernels between packed bits and the fp32 pool.
+ * bits[n][512]: site j of individual i is bit j % 8 of byte i * 8 + j / 8.  pgan_parse_alignments runs on the host
+ * (threads worker threads), fills status[k] (0 ok, 1 unreadable, 2 wrong number of values, 3 a site value other than
+ * 0 / 1) and returns the number of failed pairs.  pgan_unpack_sites: sites[n][1][64][64] = scale * bit + shift (scale 2,
+ * shift -1 is --normalize, src/train_wgan_v2.py:453,519-521).  pgan_pack_sites: bit = (x >= 0.5). */
+int pgan_parse_alignments(const char* const* sites_paths, const char* const* pos_paths, int n, unsigned char* bits,
+                          float* pos, int* status, int threads);
+int pgan_unpack_sites(const unsigned char* bits, float* sites, long long n, float scale, float shift, hipStream_t st);
+int pgan_pack_sites(const float* sites, unsigned char* bits, long long n, hipStream_t st);
+
+/* ---- one step as a hipGraph (the reference launches its step op by op from Python, src/train_wgan_v2.py:534-634):
+ * begin capture on st, enqueue the step once through the entry points above (side streams join st through events),
+ * end -> executable graph; launch replays it on st; destroy frees it.  No kernel runs between begin and end. */
+int pgan_step_graph_begin(hipStream_t st);
+int pgan_step_graph_end(hipStream_t st, void** graph_exec);
+int pgan_step_graph_launch(void* graph_exec, hipStream_t st);
+int pgan_step_graph_destroy(void* graph_exec);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,4 +322,33 @@ int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStr
     return pgan_launch_status();
 }
 
+// One training step (any sequence of the entry points above, on `st` and on streams forked from it with events) as
+// a hipGraph: begin, enqueue the step once, end -> executable graph; launch replays it.  Relaxed capture mode:
+// other host threads may keep calling HIP.  Nothing is launched between begin and end.
+int pgan_step_graph_begin(hipStream_t st) {
+    return hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess ? PGAN_OK : PGAN_ELAUNCH;
+}
+
+int pgan_step_graph_end(hipStream_t st, void** graph_exec) {
+    if (!graph_exec) return PGAN_EINVAL;
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(st, &g) != hipSuccess || !g) return PGAN_ELAUNCH;
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return PGAN_ELAUNCH;
+    *graph_exec = ex;
+    return PGAN_OK;
+}
+
+int pgan_step_graph_launch(void* graph_exec, hipStream_t st) {
+    if (!graph_exec) return PGAN_EINVAL;
+    return hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), st) == hipSuccess ? PGAN_OK : PGAN_ELAUNCH;
+}
+
+int pgan_step_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return PGAN_EINVAL;
+    return hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)) == hipSuccess ? PGAN_OK : PGAN_ELAUNCH;
+}
+
 }  // extern "C"

@@ -71,6 +71,13 @@ _SIGS = {
     "pgan_ct1d_down": [P, P, P, I, I, I, I, P],
     "pgan_ct1d_wgrad": [P, P, P, I, I, I, I, P],
     "pgan_gemm": [P, P, P, I, I, I, I, P],
+    "pgan_parse_alignments": [P, P, I, P, P, P, I],
+    "pgan_unpack_sites": [P, P, L, F, F, P],
+    "pgan_pack_sites": [P, P, L, P],
+    "pgan_step_graph_begin": [P],
+    "pgan_step_graph_end": [P, ctypes.POINTER(ctypes.c_void_p)],
+    "pgan_step_graph_launch": [P, P],
+    "pgan_step_graph_destroy": [P],
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
@@ -131,6 +138,32 @@ def _stream():
     if _raw_stream is not None:
         return _raw_stream(_DEVICE_INDEX[0])
     return torch.cuda.current_stream(_DEVICE_INDEX[0]).cuda_stream
+
+
+class StepGraph:
+    """A step recorded through the library's own capture entry points (no torch graph machinery): everything the
+    `with` block enqueues on the current stream becomes one executable hipGraph; launch() replays it there."""
+
+    def __init__(self):
+        self.handle = ctypes.c_void_p()
+
+    def __enter__(self):
+        _check(_lib.pgan_step_graph_begin(_stream()), "pgan_step_graph_begin")
+        return self
+
+    def __exit__(self, *exc):
+        rc = _lib.pgan_step_graph_end(_stream(), ctypes.byref(self.handle))
+        if exc[0] is None:
+            _check(rc, "pgan_step_graph_end")
+        return False
+
+    def launch(self):
+        _check(_lib.pgan_step_graph_launch(self.handle, _stream()), "pgan_step_graph_launch")
+
+    def __del__(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            _lib.pgan_step_graph_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 def _check(rc: int, what: str):

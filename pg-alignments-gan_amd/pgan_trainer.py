@@ -82,6 +82,14 @@ class FusedTrainer:
             self.ops.affine(self.pool_p, 2.0, -1.0, self.pool_p)
         self.cursor.zero_()
 
+    def set_pool_packed(self, bits, pos, normalize: bool = False) -> None:
+        """set_pool from packed alignments (bits [P, 512] uint8, positions [P, 64] float32, see alignment_slab):
+        768 bytes per alignment cross to the GPU through pinned double buffers and are expanded there."""
+        import alignment_slab
+        assert bits.shape[0] == pos.shape[0] and bits.shape[0] >= self.eng.B
+        self.pool_s, self.pool_p = alignment_slab.to_device(bits, pos, self.dev, normalize)
+        self.cursor.zero_()
+
     def shuffle_pool(self, rows: bool = False) -> None:
         """Start of an epoch: new random order of the pool (the loader's on_epoch_end shuffle,
         src/train_wgan_v2.py:239-242) and, with rows=True, an independent permutation of the 64

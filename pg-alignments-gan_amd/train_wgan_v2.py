@@ -78,8 +78,23 @@ class DataGeneratorDisk(object):
         pos = np.array(pos, dtype=np.float32).reshape(len(sel), 64) if sel else np.zeros((0, 64), np.float32)
         return torch.FloatTensor(sites[:, None]), torch.FloatTensor(pos[:, None])
 
+    def load_packed(self, threads=8):
+        """Every selected alignment, in index order, through the native parser: (bits [num_in, 512] uint8,
+        positions [num_in, 64] float32); alignment_slab.NotPackable if a sites file is not 0 / 1."""
+        import alignment_slab
+        return alignment_slab.parse_pairs([self.sites[u] for u in self.indices],
+                                          [self.positions[u] for u in self.indices], threads)
+
     def load_all(self):
-        """Every selected alignment, in index order: (num_in,1,64,64), (num_in,1,64) fp32."""
+        """Every selected alignment, in index order: (num_in,1,64,64), (num_in,1,64) fp32.  Native parser when the
+        sites are 0 / 1 (the values equal np.loadtxt's bit for bit), np.loadtxt otherwise."""
+        import alignment_slab
+        try:
+            bits, pos = self.load_packed()
+            return (torch.from_numpy(alignment_slab.unpack_numpy(bits)[:, None]),
+                    torch.from_numpy(pos[:, None].copy()))
+        except alignment_slab.NotPackable:
+            pass
         s = np.empty((len(self.indices), 1, 64, 64), np.float32)
         p = np.empty((len(self.indices), 1, 64), np.float32)
         for i, u in enumerate(self.indices):
@@ -235,6 +250,9 @@ def parse_args(argv=None):
     p.add_argument("--normalize", action="store_true", help="normalize inputs to [-1, 1] for tanh")
     p.add_argument("--shuffle_inds", action="store_true", help="shuffle individuals in each input alignment")
     p.add_argument("--verbose", action="store_true", help="verbose output to log")
+    p.add_argument("--slab", default="None",
+                   help="packed copy of the selected input (bits + positions): read if the file exists, else written "
+                        "after parsing --idir; later runs start without touching the CSV files")
     p.add_argument("--local_bn", action="store_true",
                    help="several GPUs: BatchNorm statistics of each GPU's own samples instead of the global batch")
     args = p.parse_args(argv)
@@ -326,10 +344,28 @@ def main(argv=None):
 
     if world > 1:
         random.seed(1234)             # the ranks pick the same --num_in files
-    data = DataGeneratorDisk(args.idir, num_in=num_in, batch_size=batch)
-    sites, pos = data.load_all()
+    import alignment_slab
+    bits = None
+    if args.slab != "None" and os.path.exists(args.slab):
+        bits, pos64 = alignment_slab.read_slab(args.slab)
+        if bits.shape[0] < num_in:
+            raise ValueError(f"{args.slab} holds {bits.shape[0]} alignments, --num_in asks for {num_in}")
+        bits, pos64 = np.asarray(bits[:num_in]), np.asarray(pos64[:num_in])
+    else:
+        data = DataGeneratorDisk(args.idir, num_in=num_in, batch_size=batch)
+        try:
+            bits, pos64 = data.load_packed()
+            if args.slab != "None" and rank == 0:
+                alignment_slab.write_slab(args.slab, bits, pos64)
+        except alignment_slab.NotPackable:      # sites other than 0 / 1: the reference's float loader
+            sites, pos = data.load_all()
+    if bits is not None:
+        sites = torch.from_numpy(alignment_slab.unpack_numpy(bits)[:, None])
+        pos = torch.from_numpy(pos64[:, None].copy())
     if world > 1:
         random.seed()
+    if args.mono_switch or args.label_smooth:
+        bits = None                       # host-side float transforms follow: the pool is set from the fp32 tensors
     if args.mono_switch:
         sites, pos = switch_monomorphic(sites, pos, 0, 10)
     if args.label_smooth:
@@ -352,11 +388,11 @@ def main(argv=None):
         import torch.distributed as dist
         for flat in (trainer.eng.G.flat, trainer.eng.D.flat):
             dist.broadcast(flat, src=0)
-        pool_s, pool_p = sites[rank::world], pos[rank::world]
-    else:
-        pool_s, pool_p = sites, pos
     trainer.weights_changed()
-    trainer.set_pool(pool_s, pool_p, normalize=normalize)
+    if bits is not None:
+        trainer.set_pool_packed(bits[rank::world], pos64[rank::world], normalize=normalize)
+    else:
+        trainer.set_pool(sites[rank::world], pos[rank::world], normalize=normalize)
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
     else:

@@ -57,3 +57,26 @@ def test_train_cli_writes_2dswd(tmp_path):
     iters = 2 * ((96 // 8) // 5)
     assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 1     # saved before epoch 2's evaluation
 
+
+
+def test_train_cli_slab_cache(tmp_path):
+    """--slab: the first run parses the CSV directory and writes the packed copy, the second run trains from it with
+    the directory gone."""
+    import shutil
+
+    import alignment_slab
+    import train_wgan_v2 as tw
+    idir, odir, slab = tmp_path / "sims", tmp_path / "out", tmp_path / "cache.slab"
+    idir.mkdir()
+    _write_sims(str(idir), 48)
+    argv = ["--idir", str(idir), "--odir", str(odir), "--use_cuda", "--num_in", "48", "--batch_size", "8",
+            "--epochs", "1", "--save_freq", "1", "--critic_iter", "5", "--slab", str(slab)]
+    tw.main(argv)
+    bits, pos = alignment_slab.read_slab(str(slab))
+    assert bits.shape == (48, 512) and pos.shape == (48, 64)
+    rs, _ = orc.synthetic_alignments(48, 5)
+    assert sorted(map(bytes, alignment_slab.pack_numpy(rs[:, 0].numpy()))) == sorted(map(bytes, np.asarray(bits)))
+    shutil.rmtree(idir)
+    tw.main(argv)
+    g = torch.load(odir / "generator_model_0001.pt", weights_only=True)
+    assert all(bool(torch.isfinite(v.float()).all()) for v in g.values())

@@ -509,3 +509,39 @@ def test_generator_small_ops(hip):
     REF.gemm_tn(*d64(z, da), want)
     hip.gemm_tn(*gpu(z, da), got)
     close("gemm_tn", got, want)
+
+
+def test_step_graph_capture_and_replay(hip):
+    """pgan_step_graph_*: a short chain of launches (with a fork onto a second stream and back) recorded once and
+    replayed equals the same chain launched eagerly; nothing runs during the recording."""
+    import pgan_hip
+    rng = np.random.default_rng(21)
+    x0 = rnd(rng, 4096).to(DEV)
+    x, y, z = x0.clone(), torch.zeros(4096, device=DEV), torch.zeros(4096, device=DEV)
+    main, other = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def chain():
+        hip.affine(x, 1.5, 0.25, x)          # x <- 1.5 x + 0.25
+        other.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(other):
+            hip.affine(x, 2.0, 0.0, y)       # y <- 2 x     (second stream)
+        hip.affine(x, -1.0, 1.0, z)          # z <- 1 - x
+        torch.cuda.current_stream().wait_stream(other)
+        hip.affine(y, 1.0, 3.0, y)           # y <- y + 3
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main):
+        g = pgan_hip.StepGraph()
+        with g:
+            chain()
+        main.synchronize()
+        assert torch.equal(x, x0) and float(y.abs().sum()) == 0.0      # recorded, not run
+        for _ in range(3):
+            g.launch()
+        main.synchronize()
+    want = x0.clone()
+    for _ in range(3):
+        want = 1.5 * want + 0.25
+    close("graph.x", x, want.double().cpu())
+    close("graph.y", y, (2 * want + 3).double().cpu())
+    close("graph.z", z, (1 - want).double().cpu())
+    del g
