@@ -38,10 +38,11 @@ int pgan_conv_up(const float* S, const float* W, float* L, int N, int Cs, int Cl
 /* dW = sum_n S[n] (x) L[r(n)] (weight gradient of both of the above; aten::convolution_backward
  * reached from src/train_wgan_v2.py:609,633).  r(n) = n for n < n_keep, n + n_swap for
  * n < n_keep + n_swap, n - n_swap otherwise (pairs the engine's adjoint slots with its activation
- * slots).  ws: scratch of pgan_conv_wgrad_workspace_floats(...) floats. */
+ * slots).  accumulate != 0 adds to dW instead of overwriting it (a gradient assembled from several passes over
+ * different sample ranges).  ws: scratch of pgan_conv_wgrad_workspace_floats(...) floats. */
 long long pgan_conv_wgrad_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                    int hs, int n_keep, int n_swap, hipStream_t st);
+                    int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
 
 /* out[c] (+)= sum of part[r * ld + c] over rows [r0,r1) and [r2,r3), c < C <= ld: finishes the
  * per-sample partial sums of the norm-parameter and 1-D-tower gradients. */
@@ -61,7 +62,7 @@ int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs,
 /* weight gradient with both operands split in the kernel (same arguments and scratch contract as pgan_conv_wgrad) */
 long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                       int hs, int n_keep, int n_swap, hipStream_t st);
+                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
 /* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant"; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
 

@@ -788,11 +788,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len) {
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len,
+                                   int accumulate) {
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= len) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + z * len + i4 * 4);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i4 * 4);
     *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
 }
 
@@ -1068,7 +1070,7 @@ int wgrad_splits(int N, int Cs, int Cl) {
 }
 template <int HS>
 int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
-                 int n_keep, int n_swap, hipStream_t st) {
+                 int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (Cs % WG_BM || Cl % WG_CLB) return PGAN_EINVAL;
     const int chunks = PixTile<HS, WG_PIXC>::ntiles(N);
     const int ns = wgrad_splits<HS>(N, Cs, Cl);
@@ -1077,7 +1079,7 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
     if (ns * len > ws_floats) return PGAN_EINVAL;
     dim3 grid((Cs / WG_BM) * (Cl / WG_CLB), ns);
     conv_wgrad_kernel<HS, WG_BM, WG_CLB, WG_PIXC><<<grid, 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb);
-    slab_reduce_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len);
+    slab_reduce_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len, accumulate);
     return pgan_launch_status();
 }
 
@@ -1145,20 +1147,20 @@ long long pgan_conv_wgrad_workspace_floats(int N, int Cs, int Cl, int hs) {
     return (long long)ns * Cs * Cl * 16;
 }
 
-// dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)],  r(n) = n (n < n_keep), n + n_swap (n < n_keep + n_swap), else n - n_swap.
+// dW[Cs,Cl,4,4] (+)= sum_n S[n] (x) L[r(n)],  r(n) = n (n < n_keep), n + n_swap (n < n_keep + n_swap), else n - n_swap.
 int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                    int hs, int n_keep, int n_swap, hipStream_t st) {
+                    int hs, int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
     if (Cl == 1) {
         if (hs != 32 || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
         conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
-        rows_sum_kernel<<<(Cs * 16 + 31) / 32, 256, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, 0);
+        rows_sum_kernel<<<(Cs * 16 + 31) / 32, 256, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, accumulate);
         return pgan_launch_status();
     }
     switch (hs) {
-        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
-        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
-        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
         default: return PGAN_EINVAL;
     }
 }

@@ -632,11 +632,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len) {
+__global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len,
+                                int accumulate) {
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 * 4 >= len) return;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < nslab; ++z) s += *reinterpret_cast<const f32x4*>(slab + z * len + i4 * 4);
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(out + i4 * 4);
     *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
 }
 
@@ -653,7 +655,7 @@ int wgrad_x3_splits(int N, int Cs, int Cl) {
 
 template <int HS>
 int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
-                 int n_keep, int n_swap, hipStream_t st) {
+                 int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (Cs % 64 || Cl % 8) return PGAN_EINVAL;
     const int chunks = PixTile<HS, 64>::ntiles(N);
     const int ns = wgrad_x3_splits<HS>(N, Cs, Cl);
@@ -661,7 +663,7 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
     const int64_t len = (int64_t)Cs * Cl * 16;
     if (ns * len > ws_floats) return PGAN_EINVAL;
     conv_wgrad_x3_kernel<HS><<<dim3((Cs / 64) * (Cl / 8), ns), 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb);
-    slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len);
+    slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len, accumulate);
     return pgan_launch_status();
 }
 
@@ -791,12 +793,12 @@ long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs) {
 
 // dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)] as pgan_conv_wgrad, with the six-product bf16 split of both operands.
 int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                       int hs, int n_keep, int n_swap, hipStream_t st) {
+                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
     switch (hs) {
-        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
-        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
-        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, st);
+        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
         default: return PGAN_EINVAL;
     }
 }

@@ -213,6 +213,9 @@ class Engine:
         self.bn_world = 1
         import os
         self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
+        # weight gradients of the Wasserstein samples right after their backward, the penalised samples' share added
+        # later (two half-size passes per stage instead of one): measured slightly slower, kept as an option
+        self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "0") == "1"
         self._bn_parts = {}
         # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
         # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
@@ -563,6 +566,8 @@ class Engine:
                 self.side.wait_mark()
                 o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
                 self._d_backward1(0, 2 * B, 0, 0, None)
+                for k in (range(4, 0, -1) if self.split_wgrad else ()):
+                    o.conv_wgrad(self.dJ[k][:2 * B], self.dH[k - 1][:2 * B], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
             self._d_forward2d(2 * B, NS)
             self._d_backward1(2 * B, NS, NS - NP, NS, self.G0[:NP])
@@ -601,7 +606,11 @@ class Engine:
             # over all slots) runs on its own stream beside the rest of the chain
             self.wside.fork()
             with self.wside:
-                o.conv_wgrad(self.dJ[k], self.dH[k - 1], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"], NS - NP, NP)
+                dw = Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"]
+                if two_chains and self.split_wgrad:
+                    o.conv_wgrad(self.dJ[k][2 * B:], self.dH[k - 1][2 * B:], dw, 0, NP, accumulate=True)
+                else:
+                    o.conv_wgrad(self.dJ[k], self.dH[k - 1], dw, NS - NP, NP)
                 if self.grad_ready is not None:
                     self.grad_ready(f"twod_conv_layers.{3 * (k - 1)}.weight")
             if k > 1:

@@ -35,11 +35,11 @@ P, I, L, F = c_void_p, c_int, c_longlong, c_float
 _SIGS = {
     "pgan_conv_down": [P, P, P, I, I, I, I, P],
     "pgan_conv_up": [P, P, P, I, I, I, I, I, P],
-    "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, P],
+    "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, I, P],
     "pgan_conv_x3_prep": [P, P, I, I, P],
     "pgan_conv_down_x3": [P, P, P, I, I, I, I, P],
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
-    "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, P],
+    "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
@@ -257,7 +257,7 @@ class HipOps:
             return
         _check(_lib.pgan_conv_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, hs, act, _stream()), "pgan_conv_up")
 
-    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0):
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False):
         N, Cs, hs = ya.shape[0], ya.shape[1], ya.shape[2]
         Cl = x.shape[1]
         if n_keep is None:
@@ -268,13 +268,13 @@ class HipOps:
             if need < 0 or need > self.ws.numel():
                 raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
             _check(_lib.pgan_conv_wgrad_x3(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs,
-                                           n_keep, n_swap, _stream()), "pgan_conv_wgrad_x3")
+                                           n_keep, n_swap, int(accumulate), _stream()), "pgan_conv_wgrad_x3")
             return
         need = _lib.pgan_conv_wgrad_workspace_floats(N, Cs, Cl, hs)
         if need < 0 or need > self.ws.numel():
             raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
         _check(_lib.pgan_conv_wgrad(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs,
-                                    n_keep, n_swap, _stream()), "pgan_conv_wgrad")
+                                    n_keep, n_swap, int(accumulate), _stream()), "pgan_conv_wgrad")
 
     def rows_reduce(self, part, out, r0, r1, r2, r3, accumulate=False):
         C = part.shape[1]

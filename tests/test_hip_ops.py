@@ -167,11 +167,15 @@ def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
     REF.conv_wgrad(*d64(ya, x), want, keep, swap)
     got = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
     hip.wgrad_x3 = pipe == "bf16"
+    base = rnd(rng, Cs, Cl, 4, 4)
+    acc = base.to(DEV)
     try:
         hip.conv_wgrad(*gpu(ya, x), got, keep, swap)
+        hip.conv_wgrad(*gpu(ya, x), acc, keep, swap, accumulate=True)
     finally:
         hip.wgrad_x3 = True
     close("conv_wgrad", got, want)
+    close("conv_wgrad.accumulate", acc, want + base.double())
 
 
 @pytest.mark.parametrize("N", [1, 3])
@@ -192,6 +196,9 @@ def test_conv_c1(hip, N, act):
     close("conv_up_c1", got, want)
     want = torch.zeros(Cs, 1, 4, 4, dtype=torch.float64)
     REF.conv_wgrad(*d64(y, x), want, 1, 1 if N == 3 else 0)
+    acc = torch.ones(Cs, 1, 4, 4, device=DEV)
+    hip.conv_wgrad(*gpu(y, x), acc, 1, 1 if N == 3 else 0, accumulate=True)
+    close("conv_wgrad_c1.accumulate", acc, want + 1)
     got = torch.full((Cs, 1, 4, 4), float("nan"), device=DEV)
     hip.conv_wgrad(*gpu(y, x), got, 1, 1 if N == 3 else 0)
     close("conv_wgrad_c1", got, want)

@@ -42,7 +42,7 @@ class TorchOps:
             o = torch.tanh(o)
         x.copy_(o)
 
-    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0):
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False):
         """dw[cs,cl,kh,kw] = sum_n sum_{oh,ow} ya[n,cs,oh,ow] * x[r(n),cl,2oh-1+kh,2ow-1+kw] where
         r(n) = n for n < n_keep, n + n_swap for n_keep <= n < n_keep + n_swap, n - n_swap after."""
         n = ya.shape[0]
@@ -52,7 +52,8 @@ class TorchOps:
         if n_swap:
             idx = torch.where(idx < n_keep, idx, torch.where(idx < n_keep + n_swap, idx + n_swap, idx - n_swap))
         xr = x[idx]
-        dw.copy_(torch.nn.grad.conv2d_weight(xr, dw.shape, ya, stride=2, padding=1))
+        g = torch.nn.grad.conv2d_weight(xr, dw.shape, ya, stride=2, padding=1)
+        dw.copy_(dw + g if accumulate else g)
 
     # ---------------- GroupNorm(1, C) + LeakyReLU family (per-sample statistics) ----------------
     def gn_fwd(self, a, gamma, beta, h, stats):
