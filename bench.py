@@ -161,7 +161,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=20, help="back-to-back launches per shape for per-kernel timing")
     ap.add_argument("--no-fp32-pipe", action="store_true", help="skip the side measurement with every convolution on the fp32 matrix pipe")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="one untimed iteration to collect the launch shapes, then only the isolated per-shape timing "
+                         "(the command to put under rocprofv3 --kernel-trace --stats when comparing its per-kernel "
+                         "average durations with roofline.per_shape)")
     args = ap.parse_args()
+    if args.kernels_only:
+        args.steps, args.warmup, args.no_graph, args.no_cpu_baseline, args.no_fp32_pipe = 1, 0, True, True, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
