@@ -422,13 +422,16 @@ class Engine:
         up = self.gdX
         for i in range(4, 0, -1):
             w = G[f"twod_conv_layers.{3 * i}.weight"]
-            o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
+            self.wside.fork()
+            with self.wside:      # the weight gradient beside the input-gradient chain
+                o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
             o.conv_down(up, w, self.gdH[i])
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
             self._bn_bwd(n, self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
                          dG[n + ".weight"], dG[n + ".bias"])
             up = self.gdA[i]
         o.gemm_tn(self.Z, self.gdA[1].view(self.B, -1), dG["twod_conv_layers.0.weight"].view(self.latent, -1))
+        self.wside.join()
 
     def _gen_backward_1d(self, xp, dxp) -> None:
         o, G, dG = self.ops, self.G.p, self.G.g
