@@ -187,6 +187,48 @@ class FusedTrainer:
             self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
     def _iteration_body(self) -> None:
+        if self.sync_bn:
+            return self._iteration_body_ahead()
+        return self._iteration_body_one_ahead()
+
+    def _iteration_body_ahead(self) -> None:
+        """Variant for BatchNorm statistics over several ranks: every generator forward then holds 8 small
+        collectives, a latency chain of about a critic step's length.  All of the iteration's generator forwards
+        (one per critic step, then the generator step's own) are therefore enqueued up front on their stream and run
+        as far ahead as they can; each critic step waits for its own fakes only.  z is drawn in the reference's order
+        and the running statistics see the forwards in that order."""
+        e, o = self.eng, self.ops
+        B, gs, n = e.B, e.gside, self.critic_iter
+        if getattr(self, "fa_s", None) is None or len(self.fa_s) != n:
+            self.fa_s = [torch.zeros(B, 1, 64, 64, device=self.dev) for _ in range(n)]
+            self.fa_p = [torch.zeros(B, 1, 64, device=self.dev) for _ in range(n)]
+            self.fa_done = [torch.cuda.Event() if self.dev.type == "cuda" else None for _ in range(n)]
+        gs.fork()
+        with gs:
+            for i in range(n):
+                o.philox(e.Z, self.rng_z, True)
+                e.gen_forward_resident(self.fa_s[i], self.fa_p[i])
+                if self.fa_done[i] is not None:
+                    self.fa_done[i].record()
+            o.philox(e.Z, self.rng_z, True)
+            e.gen_forward_resident(e.gXs, e.gXp)       # its activations stay in the workspace for the generator step
+        for i in range(n):
+            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
+            if e.loss == "gp":
+                o.philox(e.tbuf, self.rng_t, False)
+            if self.fa_done[i] is not None:
+                torch.cuda.current_stream().wait_event(self.fa_done[i])     # this step's fakes are complete
+            e.X0[B:2 * B].copy_(self.fa_s[i])
+            e.P0[B:2 * B].copy_(self.fa_p[i])
+            e.critic_grads_resident(run_generator=False)
+            self._allreduce(e.D.gflat)
+            e.adam_d()
+        gs.join()
+        e.generator_grads_resident(forward_done=True)
+        self._allreduce(e.G.gflat)
+        e.adam_g()
+
+    def _iteration_body_one_ahead(self) -> None:
         """The generator's weights do not change during the critic steps, so every generator forward
         (a chain of small launches) is made one step ahead on its own stream, beside the previous
         critic step's large kernels: fakes alternate between two buffers, and the generator step's own
