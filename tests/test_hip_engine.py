@@ -244,3 +244,34 @@ def test_one_adam_step_matches_oracle(hip):
         got = (eng.D.p[k].cpu().double() - before[k])[solid]
         ulp = 1.2e-7 * before[k][solid].abs() + 1e-9   # the step is added to an fp32 weight
         assert bool(((got - step).abs() <= 2 * ulp).all()), k
+
+
+def test_two_chain_critic_step_equals_single_chain(hip):
+    """gp critic step at the benchmark batch: the two concurrent sample chains (Wasserstein | penalty, on two
+    streams) give what the one-chain order gives on the same inputs -- stage activations of every slot to rounding
+    (launch sizes differ, so the split-K summation order does), gradients to 2e-6 -- on repeated calls."""
+    from pgan_engine import Engine
+    B = 64
+    engs = []
+    for two in (True, False):
+        e = Engine(hip, B, DEV)
+        e.two_chains = two
+        e.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+        e.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+        engs.append(e)
+    a, b = engs
+    for it in range(4):
+        rs, rp = orc.synthetic_alignments(B, 100 + it)
+        g = torch.Generator().manual_seed(it)
+        z, t = torch.randn(B, 128, 1, 1, generator=g), torch.rand(B, generator=g)
+        for e in engs:
+            e.critic_grads(rs.to(DEV), rp.to(DEV), z.to(DEV), t.to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(a.X0[:3 * B], b.X0[:3 * B])
+        for k in range(1, 5):
+            for buf in ("dA", "dH"):
+                x, y = getattr(a, buf)[k], getattr(b, buf)[k]
+                err = float((x - y).abs().max()) / float(y.abs().max())
+                assert err < 2e-5, (it, buf, k, err)
+        assert rel_err(a.D.gflat, b.D.gflat) < 2e-6
+        assert torch.allclose(a.closs, b.closs, rtol=1e-5, atol=1e-6)
