@@ -105,7 +105,8 @@ def test_critic_step_vs_reference_golden(hip, fname, loss):
 
 
 @pytest.mark.parametrize("loss,act,B", [("gp", "tanh", 8), ("div", "tanh", 8), ("gp", "sigmoid", 64),
-                                        ("div", "sigmoid", 32)])
+                                        ("div", "sigmoid", 32), ("gp", "sigmoid", 1), ("div", "sigmoid", 3),
+                                        ("gp", "tanh", 5)])
 def test_critic_grads_vs_oracle(hip, loss, act, B):
     """Every discriminator gradient within 1e-5 (norm-wise) of the fp64 oracle evaluated on the same
     LeakyReLU linear region, at test size and at the benchmark's batch size."""
@@ -129,7 +130,8 @@ def test_critic_grads_vs_oracle(hip, loss, act, B):
     assert abs(float(eng.closs[0]) - float(w)) <= 1e-5 * max(1.0, abs(float(w)))
     for k, gr in grads.items():
         if float(gr.norm()) == 0:
-            assert float(eng.D.g[k].abs().max()) < 1e-9, k
+            # exactly 0 in the oracle (+1/B and -1/B seeds cancel); fp32 sums of 1/B leave rounding when B is not 2^k
+            assert float(eng.D.g[k].abs().max()) < (1e-9 if B & (B - 1) == 0 else 1e-6), k
             continue
         e = rel_err(eng.D.g[k], gr)
         print(f"{loss} {k}: {e:.2e}")
@@ -153,7 +155,7 @@ def test_generator_step_vs_reference_golden(hip, act):
         check_summary(g, f"grad.{k}", eng.G.g[k], rtol=5e-3, what=f"gen {act}:")
 
 
-@pytest.mark.parametrize("act,B", [("sigmoid", 8), ("tanh", 8), ("sigmoid", 64)])
+@pytest.mark.parametrize("act,B", [("sigmoid", 8), ("tanh", 8), ("sigmoid", 64), ("sigmoid", 1), ("tanh", 3)])
 def test_generator_grads_vs_oracle_fp64(hip, act, B):
     seed = 4321
     eng, gp_, dp = make_engine(hip, B, "gp", act, seed)
