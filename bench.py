@@ -297,6 +297,11 @@ def main():
                             achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             traffic=traffic, traffic_shape=traffic_of,
                             algorithmic_tflops=round(alg, 3),
+                            algorithmic_frac_of_fp32_mfma_peak=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                            note=("achieved / peak / frac price the bf16 MFMA work actually executed (6 partial products "
+                                  "per fp32 product) against the dense bf16 peak; algorithmic_* price the fp32 convolution "
+                                  "flops (2 N Cs Cl 16 hs^2 per launch) against the fp32 matrix pipe's 157.3 TFLOP/s"
+                                  if pipe[dom] == "bf16" else "fp32 convolution flops on the fp32 matrix pipe"),
                             executed_per_algorithmic_flop=mult,
                             sustained_on_random_operands=SUSTAINED_RANDOM_TFLOPS[pipe[dom]],
                             frac_of_sustained=round(ach / SUSTAINED_RANDOM_TFLOPS[pipe[dom]], 4),
