@@ -333,9 +333,17 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # generator
     # ------------------------------------------------------------------------------------------
+    def _fresh(self) -> None:
+        """Entry points call this first: a critic step that raised between preparing and releasing the weight planes
+        must not leave later calls reading planes of outdated weights."""
+        rel = getattr(self.ops, "release_weights", None)
+        if rel is not None:
+            rel()
+
     def gen_forward(self, z: torch.Tensor, out_s: torch.Tensor, out_p: torch.Tensor) -> None:
         """(sites, positions) = G(z), BatchNorm in training mode (layers.py:143-147).  Activations
         stay in the generator workspace for a following gen_backward."""
+        self._fresh()
         if z.data_ptr() != self.Z.data_ptr():
             self.Z.copy_(z.reshape(self.B, self.latent))
         self.g_batches_tracked += 1
@@ -475,6 +483,7 @@ class Engine:
         """score = D(xs, xp) for up to 2B samples (layers.py:487-493)."""
         n = xs.shape[0]
         o = self.ops
+        self._fresh()
         self.X0[:n].copy_(xs)
         self.P0[:n].copy_(xp)
         self._d_forward2d(0, n)
@@ -536,6 +545,7 @@ class Engine:
         z in Z, t in tbuf (and, with run_generator=False, the fake batch in X0[B:2B] / P0[B:2B])."""
         o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
         Dp, Dg = self.D.p, self.D.g
+        self._fresh()
         cw, cb, gw, gb = self._d1d_params(Dp)
         dcw, dcb, dgw, dgb = self._d1d_params(Dg)
         if run_generator:
@@ -646,6 +656,7 @@ class Engine:
         activations in the generator workspace, from gen_forward_resident(self.gXs, self.gXp))."""
         o, B = self.ops, self.B
         Dp = self.D.p
+        self._fresh()
         cw, cb, gw, gb = self._d1d_params(Dp)
         a1 = [a[:B] for a in self.d1A]
         if not forward_done:
