@@ -2,9 +2,11 @@
 of every slot must agree bit for bit, gradients to rounding."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pg-alignments-gan_amd")]
 import torch
-import dcwgan_oracle as orc
+import numpy as np
+from bench import synthetic_pool
+from pgan_engine import disc_param_shapes, gen_param_shapes
 from pgan_engine import Engine
 from pgan_hip import HipOps
 dev = torch.device("cuda", 0)
@@ -14,11 +16,16 @@ engs = []
 for two in (True, False):
     e = Engine(ops, B, dev)
     e.two_chains = two
-    e.D.load(orc.make_params(orc.disc_param_shapes(), 7)); e.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    gen = torch.Generator().manual_seed(7)
+    for store, shapes in ((e.G, gen_param_shapes()), (e.D, disc_param_shapes())):
+        for k, sh in shapes.items():
+            v = ((torch.ones(sh) if k.endswith("weight") and not k.startswith("out") else torch.zeros(sh)) if len(sh) == 1
+                 else (torch.rand(sh, generator=gen) * 2 - 1) / int(np.prod(sh[1:])) ** 0.5)
+            store.p[k].copy_(v)
     engs.append(e)
 bad = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
-    rs, rp = orc.synthetic_alignments(B, 100 + it)
+    rs, rp = synthetic_pool(B, 100 + it)
     g = torch.Generator().manual_seed(it)
     z, t = torch.randn(B, 128, 1, 1, generator=g), torch.rand(B, generator=g)
     for e in engs:

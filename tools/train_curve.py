@@ -2,14 +2,14 @@
 pairs, trains with --plot and prints the 2DSWD of every saved epoch (w_dist_pca.txt) with the wall time."""
 import os, sys, time, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pg-alignments-gan_amd")]
 import numpy as np
-import dcwgan_oracle as orc
+from bench import synthetic_pool
 import train_wgan_v2 as tw
 n, epochs, every = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 idir, odir = "/tmp/curve_sims", "/tmp/curve_out"
 shutil.rmtree(idir, ignore_errors=True); os.makedirs(idir)
-rs, rp = orc.synthetic_alignments(n, 11)
+rs, rp = synthetic_pool(n, 11)
 for i in range(n):
     np.savetxt(f"{idir}/{i}_sites.csv", rs[i, 0].numpy().astype(int), fmt="%d", delimiter=",")
     np.savetxt(f"{idir}/{i}_pos.csv", rp[i, 0].numpy(), fmt="%.6f")
