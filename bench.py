@@ -154,8 +154,9 @@ def main():
     ap.add_argument("--loss", default="gp", choices=["gp", "div"])
     ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "tanh"])
     ap.add_argument("--critic-iter", type=int, default=5)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches only")
-    ap.add_argument("--graph", action="store_true", help="hipGraph replay even where eager launches are faster")
+    ap.add_argument("--route", default="auto", choices=["auto", "eager", "tape", "graph"],
+                    help="how an iteration is enqueued (auto: the fastest of the available ones, measured)")
+    ap.add_argument("--no-graph", action="store_true", help="same as --route eager")
     ap.add_argument("--local-bn", action="store_true",
                     help="several GPUs: BatchNorm statistics per GPU instead of over the global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,6 +169,8 @@ def main():
     args = ap.parse_args()
     if args.kernels_only:
         args.steps, args.warmup, args.no_graph, args.no_cpu_baseline, args.no_fp32_pipe = 1, 0, True, True, True
+    if args.no_graph:
+        args.route = "eager"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -210,27 +213,39 @@ def main():
         pg = dist.group.WORLD
         tr.attach_process_group(pg, sync_bn=not args.local_bn)
 
-    use_graph = (world == 1) and pg is None and not args.no_graph
-    step = tr.iteration
-    route = "eager launches (several GPUs: no graph capture around RCCL)" if pg is not None else "eager launches (--no-graph)"
-    if use_graph:
-        # one GPU: hipGraph replay or eager launches from the host, whichever is faster here (the same kernels on the
-        # same streams; the host enqueues an iteration in about 7 ms) -- decided on 10 untimed iterations of each
-        tr.capture()
-
-        def rate(fn, n=10):
+    # Three routes enqueue the same kernels on the same streams: eager launches from Python (about 8 ms of host time per
+    # iteration), a launch tape (the same calls replayed from a flat list, about a third of that) and a hipGraph replay
+    # (no host work, but the runtime's own placement of the graph's branches; one GPU only -- no capture around RCCL).
+    # Whichever is fastest here is used: decided on 10 untimed iterations of each.
+    def rate(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
             fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n
-        t_graph, t_eager = rate(tr.replay), rate(tr.iteration)
-        use_graph = args.graph or t_graph <= t_eager
-        step = tr.replay if use_graph else tr.iteration
-        route = (f"{'hipGraph replay' if use_graph else 'eager launches'} (calibration: graph {t_graph * 1e3:.2f} ms, "
-                 f"eager {t_eager * 1e3:.2f} ms per iteration)")
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    routes = {}
+    if args.route in ("auto", "eager"):
+        routes["eager"] = tr.iteration
+    if args.route in ("auto", "tape"):
+        tr.record_tape()
+        routes["tape"] = tr.replay_tape
+    if args.route in ("auto", "graph") and world == 1 and pg is None:
+        tr.capture()
+        routes["graph"] = tr.replay
+    if not routes:
+        raise SystemExit(f"--route {args.route} is not available here")
+    times = {k: rate(fn) for k, fn in routes.items()}
+    if world > 1:      # every rank takes the same route: the slowest rank's timing decides
+        import torch.distributed as dist
+        tt = torch.tensor([times[k] for k in sorted(times)], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times = dict(zip(sorted(times), tt.tolist()))
+    best = min(times, key=times.get)
+    step, use_graph = routes[best], best == "graph"
+    route = best + " (calibration, ms per iteration: " + ", ".join(f"{k} {v * 1e3:.2f}" for k, v in sorted(times.items())) + ")"
     for _ in range(args.warmup):
         step()
 
@@ -336,9 +351,11 @@ def main():
             # the same step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
             t32 = make_trainer(HipOps(dev, precision="fp32"))
             n32 = max(5, args.steps // 2)
-            if use_graph:
+            if best == "graph":
                 t32.capture()
-            step32 = t32.replay if use_graph else t32.iteration
+            elif best == "tape":
+                t32.record_tape()
+            step32 = {"graph": t32.replay, "tape": t32.replay_tape, "eager": t32.iteration}[best]
             for _ in range(3):
                 step32()
             torch.cuda.synchronize()

@@ -28,6 +28,8 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import pgan_tape
+
 LATENT = 128
 DATA = 64
 D2_CH = (1, 64, 128, 256, 512)      # discriminator 2-D tower channels (layers.py:441-463)
@@ -139,23 +141,24 @@ class SideStream:
             self.stream = torch.cuda.Stream(device=device)
             self.mark = torch.cuda.Event()
 
+    # The waits go through pgan_tape.call: a launch tape being recorded notes them with the stream objects of now.
     def fork(self):
         if self.enabled:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            pgan_tape.call(self.stream.wait_stream, torch.cuda.current_stream())
 
     def join(self):
         if self.enabled:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            pgan_tape.call(torch.cuda.current_stream().wait_stream, self.stream)
 
     def set_mark(self):
         """Called on the side stream: remember this point."""
         if self.enabled:
-            self.mark.record(self.stream)
+            pgan_tape.call(self.mark.record, self.stream)
 
     def wait_mark(self):
         """Called on the main stream: wait for the side stream's mark."""
         if self.enabled:
-            torch.cuda.current_stream().wait_event(self.mark)
+            pgan_tape.call(torch.cuda.current_stream().wait_event, self.mark)
 
     def __enter__(self):
         if self.enabled:
@@ -665,7 +668,7 @@ class Engine:
         with self.side:   # positions: G 1-D forward, D 1-D forward, D 1-D input gradient, G 1-D backward
             if not forward_done:
                 self._gen_forward_1d(self.gXp)
-            self.P0[:B].copy_(self.gXp)
+            o.affine(self.gXp, 1.0, 0.0, self.P0[:B])                      # copy
             o.d1d_fwd(self.P0[:B], cw, cb, gw, gb, a1, self.F1[:B])
             self.side.set_mark()
             o.d1d_bwd(self.P0[:B], cw, cb, gw, gb, a1, self.coef_gen, Dp["out.weight"].view(-1)[FEAT2:],
@@ -673,7 +676,7 @@ class Engine:
             self._gen_backward_1d(self.gXp, self.dP0)
         if not forward_done:
             self._gen_forward_2d(self.gXs)
-        self.X0[:B].copy_(self.gXs)
+        o.affine(self.gXs, 1.0, 0.0, self.X0[:B])                          # copy
         self._d_forward2d(0, B)
         self.side.wait_mark()
         o.head_fwd(self.dH[4][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])

@@ -102,6 +102,42 @@ for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option):
     _fn.argtypes = [ctypes.c_char_p, c_int]
     _fn.restype = c_int
 
+import pgan_tape  # noqa: E402
+
+
+class _Enqueue:
+    """An entry point that enqueues work on a stream: callable like the ctypes function; while a launch tape is being
+    recorded (pgan_tape.tape) the call is also noted there with its resolved arguments."""
+    __slots__ = ("fn",)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        t = pgan_tape.tape
+        if t is not None:
+            t.append((self.fn, args))
+        return self.fn(*args)
+
+
+class _Lib:
+    """The loaded library with its enqueue entry points wrapped for tape recording (queries and host-side functions
+    pass through untouched)."""
+    _HOST = ("pgan_parse_alignments", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
+             "pgan_step_graph_destroy")
+
+    def __init__(self, lib):
+        self._real = lib
+        for name in _SIGS:
+            if name not in self._HOST:
+                setattr(self, name, _Enqueue(getattr(lib, name)))
+
+    def __getattr__(self, name):          # everything that was not wrapped above
+        return getattr(self._real, name)
+
+
+_lib = _Lib(_lib)
+
 
 def set_option(name: str, value: int) -> None:
     """Kernel-variant override for tuning runs (0 = size-based choice)."""
@@ -184,6 +220,7 @@ D1_PACKED = (64, 16, 16, 16, 2048, 32, 32, 32, 8192, 64, 64, 64)   # cw cb gw gb
 class HipOps:
     """Same method signatures as tests/torch_ops.TorchOps; every method writes into caller tensors."""
     name = "hip"
+    feeds_tape = True       # every enqueue goes through _Enqueue (pgan_tape)
 
     def __init__(self, device=None, ws_floats: int = 16 * 1024 * 1024, max_samples: int = 1024,
                  precision: Optional[str] = None):

@@ -18,6 +18,7 @@ from typing import Optional
 
 import torch
 
+import pgan_tape
 from pgan_engine import Engine
 
 
@@ -44,7 +45,9 @@ class FusedTrainer:
         self.pool_s: Optional[torch.Tensor] = None
         self.pool_p: Optional[torch.Tensor] = None
         self.graph = None
+        self.tape = None
         self.use_graph = False       # step(): capture on the first call, replay afterwards
+        self.use_tape = False        # step(): record a launch tape on the first call, replay it afterwards
         self.iterations = 0
         # weights change only through the engine's Adam steps here, which mark prepared weight copies stale;
         # anything else that writes parameters in place must call weights_changed()
@@ -58,10 +61,13 @@ class FusedTrainer:
         sync_bn: generator BatchNorm over the global batch (default; equals a single-device run at the global batch
         size) or over each rank's own samples (False: no collectives inside the generator)."""
         self.pg, self.dist_active = process_group, True
-        self.eng.grad_ready = self._early_reduce
+        self.tape = None
+        # collectives run on "the current stream": a launch tape replays them under the stream they were issued on
+        self.eng.grad_ready = lambda name: pgan_tape.call(self._early_reduce, name, on_current_stream=True)
         self.sync_bn = True if sync_bn is None else bool(sync_bn)
         if self.sync_bn:
-            self.eng.bn_sync, self.eng.bn_world = self._bn_allreduce, self.world
+            self.eng.bn_sync = lambda part: pgan_tape.call(self._bn_allreduce, part, on_current_stream=True)
+            self.eng.bn_world = self.world
         else:
             self.eng.bn_sync, self.eng.bn_world = None, 1
 
@@ -70,6 +76,7 @@ class FusedTrainer:
         if hasattr(self.ops, "invalidate_weight_planes"):
             self.ops.invalidate_weight_planes()
         self.graph = None
+        self.tape = None
 
     def set_pool(self, sites: torch.Tensor, pos: torch.Tensor, normalize: bool = False) -> None:
         """Real alignments resident on the device: sites [P,1,64,64], positions [P,1,64], fp32.
@@ -77,6 +84,7 @@ class FusedTrainer:
         assert sites.shape[0] == pos.shape[0] and sites.shape[0] >= self.eng.B
         self.pool_s = sites.to(self.dev, torch.float32).contiguous().clone()
         self.pool_p = pos.to(self.dev, torch.float32).contiguous().clone()
+        self.graph = self.tape = None          # both hold the old pool's addresses
         if normalize:
             self.ops.affine(self.pool_s, 2.0, -1.0, self.pool_s)
             self.ops.affine(self.pool_p, 2.0, -1.0, self.pool_p)
@@ -88,6 +96,7 @@ class FusedTrainer:
         import alignment_slab
         assert bits.shape[0] == pos.shape[0] and bits.shape[0] >= self.eng.B
         self.pool_s, self.pool_p = alignment_slab.to_device(bits, pos, self.dev, normalize)
+        self.graph = self.tape = None
         self.cursor.zero_()
 
     def shuffle_pool(self, rows: bool = False) -> None:
@@ -147,12 +156,20 @@ class FusedTrainer:
             self._allreduce(self.eng.G.gflat)
             self.eng.adam_g()
             self.iterations += 1
+        elif self.tape is not None:
+            self.replay_tape()
+        elif self.use_tape:
+            self.record_tape()
         elif self.graph is not None:
             self.replay()
         elif self.use_graph and not self.dist_active:
             self.capture()           # runs this iteration eagerly, then records the graph for the next ones
         else:
             self.iteration()
+
+    def _reduce(self, flat: torch.Tensor) -> None:
+        if self.dist_active:
+            pgan_tape.call(self._allreduce, flat, on_current_stream=True)
 
     def _bn_allreduce(self, part: torch.Tensor) -> None:
         import torch.distributed as dist
@@ -209,23 +226,23 @@ class FusedTrainer:
                 o.philox(e.Z, self.rng_z, True)
                 e.gen_forward_resident(self.fa_s[i], self.fa_p[i])
                 if self.fa_done[i] is not None:
-                    self.fa_done[i].record()
+                    pgan_tape.call(self.fa_done[i].record, gs.stream)
             o.philox(e.Z, self.rng_z, True)
             e.gen_forward_resident(e.gXs, e.gXp)       # its activations stay in the workspace for the generator step
         for i in range(n):
             o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
             if e.loss == "gp":
                 o.philox(e.tbuf, self.rng_t, False)
-            if self.fa_done[i] is not None:
-                torch.cuda.current_stream().wait_event(self.fa_done[i])     # this step's fakes are complete
-            e.X0[B:2 * B].copy_(self.fa_s[i])
-            e.P0[B:2 * B].copy_(self.fa_p[i])
+            if self.fa_done[i] is not None:       # this step's fakes are complete
+                pgan_tape.call(torch.cuda.current_stream().wait_event, self.fa_done[i])
+            o.affine(self.fa_s[i], 1.0, 0.0, e.X0[B:2 * B])          # copies
+            o.affine(self.fa_p[i], 1.0, 0.0, e.P0[B:2 * B])
             e.critic_grads_resident(run_generator=False)
-            self._allreduce(e.D.gflat)
+            self._reduce(e.D.gflat)
             e.adam_d()
         gs.join()
         e.generator_grads_resident(forward_done=True)
-        self._allreduce(e.G.gflat)
+        self._reduce(e.G.gflat)
         e.adam_g()
 
     def _iteration_body_one_ahead(self) -> None:
@@ -247,8 +264,8 @@ class FusedTrainer:
             if e.loss == "gp":
                 o.philox(e.tbuf, self.rng_t, False)
             gs.join()                                   # this step's fakes are complete
-            e.X0[B:2 * B].copy_(self.fk_s[i & 1])
-            e.P0[B:2 * B].copy_(self.fk_p[i & 1])
+            o.affine(self.fk_s[i & 1], 1.0, 0.0, e.X0[B:2 * B])      # copies
+            o.affine(self.fk_p[i & 1], 1.0, 0.0, e.P0[B:2 * B])
             gs.fork()
             with gs:                                    # next forward, beside this critic step
                 o.philox(e.Z, self.rng_z, True)
@@ -257,11 +274,11 @@ class FusedTrainer:
                 else:
                     e.gen_forward_resident(e.gXs, e.gXp)
             e.critic_grads_resident(run_generator=False)
-            self._allreduce(e.D.gflat)
+            self._reduce(e.D.gflat)
             e.adam_d()
         gs.join()
         e.generator_grads_resident(forward_done=True)
-        self._allreduce(e.G.gflat)
+        self._reduce(e.G.gflat)
         e.adam_g()
 
     def iteration(self) -> None:
@@ -292,6 +309,30 @@ class FusedTrainer:
             self._iteration_body()
         # capture records launches without running them: undo the host-side counters it bumped
         self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step = tracked, dstep, gstep
+
+    def record_tape(self) -> None:
+        """Run ONE iteration eagerly (it counts) while noting every enqueue call with its resolved arguments;
+        replay_tape() repeats them from the flat list: the same launches on the same streams as iteration(), with a
+        third of its host time.  The op backend must be the HIP library (its entry points feed the tape)."""
+        if not getattr(self.ops, "feeds_tape", False):
+            raise RuntimeError("launch tapes need the HIP op backend")
+        if getattr(self, "buf_s", None) is not None:
+            raise RuntimeError("the replay-buffer path draws host-side random indices: no tape")
+        torch.cuda.synchronize()
+        pgan_tape.tape = entries = []
+        try:
+            self._iteration_body()
+        finally:
+            pgan_tape.tape = None
+        self.iterations += 1
+        self.tape = entries
+
+    def replay_tape(self) -> None:
+        pgan_tape.replay(self.tape)
+        self.iterations += 1
+        self.eng.g_batches_tracked += self.critic_iter + 1
+        self.eng.D.step += self.critic_iter
+        self.eng.G.step += 1
 
     def replay(self) -> None:
         self.graph.replay()

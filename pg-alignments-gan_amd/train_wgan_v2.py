@@ -396,7 +396,7 @@ def main(argv=None):
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
     else:
-        trainer.use_graph = True
+        trainer.use_tape = True      # first iteration recorded as a launch tape, the rest replayed (one or several GPUs)
 
     iters_per_epoch = max(1, (num_in // (batch * world)) // critic_iter)
     for epoch in range(1, epochs + 1):

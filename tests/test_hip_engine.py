@@ -279,3 +279,38 @@ def test_two_chain_critic_step_equals_single_chain(hip):
                 assert err < 2e-5, (it, buf, k, err)
         assert rel_err(a.D.gflat, b.D.gflat) < 1e-4
         assert torch.allclose(a.closs, b.closs, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_trainer_routes_agree(hip, loss):
+    """FusedTrainer: eager iterations, hipGraph replay and launch-tape replay enqueue the same kernels on the same
+    streams -- same device RNG draws, same pool cursor, same losses, and weights equal up to the +-lr steps that
+    rounding noise (split-K atomics) gives entries with noise-level gradients."""
+    from pgan_trainer import FusedTrainer
+    B, n_it, lr = 8, 3, 5e-5
+    rs, rp = orc.synthetic_alignments(64, 9)
+    out = {}
+    for route in ("eager", "graph", "tape"):
+        tr = FusedTrainer(hip, B, DEV, loss=loss, critic_iter=2, seed=77)
+        tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+        tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+        tr.weights_changed()
+        tr.set_pool(rs, rp)
+        tr.use_graph, tr.use_tape = route == "graph", route == "tape"
+        for _ in range(n_it):
+            tr.step()
+        torch.cuda.synchronize()
+        assert (tr.graph is not None) == (route == "graph") and (tr.tape is not None) == (route == "tape")
+        out[route] = dict(d=tr.eng.D.flat.clone(), g=tr.eng.G.flat.clone(), losses=tr.losses(), cursor=int(tr.cursor),
+                          rng=tr.rng_z.clone(), nb=tr.eng.g_batches_tracked, step=(tr.eng.D.step, tr.eng.G.step),
+                          run=tr.eng.Gbuf.p["twod_conv_layers.1.running_mean"].clone())
+    a = out["eager"]
+    for route in ("graph", "tape"):
+        b = out[route]
+        assert b["cursor"] == a["cursor"] and torch.equal(b["rng"], a["rng"]) and b["nb"] == a["nb"] and b["step"] == a["step"]
+        for x, y in zip(a["losses"], b["losses"]):
+            assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (route, a["losses"], b["losses"])
+        for k in ("d", "g"):
+            assert float((a[k] - b[k]).abs().max()) <= 2 * lr * 2 * n_it, (route, k)
+            assert rel_err(b[k], a[k]) < 1e-3, (route, k)
+        assert torch.allclose(a["run"], b["run"], rtol=1e-3, atol=1e-5)
