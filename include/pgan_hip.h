@@ -96,8 +96,12 @@ int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float*
 /* ws: scratch of pgan_bn_workspace_bytes(C) bytes (large layers run as a sums launch plus an apply launch over
  * several blocks per channel). */
 long long pgan_bn_workspace_bytes(int C);
+/* groups > 1: a / h hold `groups` consecutive forward passes of B samples each; every pass gets its own batch statistics
+ * (stats: [groups][2][C]) and the running statistics step through the passes in order, as `groups` calls would (the
+ * generator forwards of one iteration, src/train_wgan_v2.py:535,622, share their weights). */
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
-                float* stats, void* ws, long long ws_bytes, int B, int C, int HW, float momentum, hipStream_t st);
+                float* stats, void* ws, long long ws_bytes, int B, int C, int HW, float momentum, int groups,
+                hipStream_t st);
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
                 float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st);
 /* The same layers (src/layers.py:93-110,119-135) with batch statistics over the global batch of a data-parallel run
@@ -105,10 +109,12 @@ int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* st
  * (forward: sum a, sum a^2; backward: sum dy, sum dy xhat), the caller adds them over the ranks (all-reduce), *_apply
  * finishes from the totals with world = number of ranks.  dgamma / dbeta are 1/world of the all-rank totals, so that
  * the later sum of the parameter gradients over the ranks gives the totals. */
-long long pgan_bn_partials(int B, int C, int HW);
-int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, hipStream_t st);
+long long pgan_bn_partials(int B, int C, int HW);                     /* backward */
+long long pgan_bn_fwd_partials(int B, int C, int HW, int groups);     /* forward */
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, hipStream_t st);
 int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
-                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, hipStream_t st);
+                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, int groups,
+                      hipStream_t st);
 int pgan_bn_bwd_sums(const float* dh, const float* h, const float* a, const float* stats, double* part, int B, int C,
                      int HW, hipStream_t st);
 int pgan_bn_bwd_apply(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,

@@ -322,39 +322,45 @@ constexpr int BT = 256;
 __global__ __launch_bounds__(BT) void bn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float* __restrict__ rmean,
                                                     float* __restrict__ rvar, float* __restrict__ h,
-                                                    float* __restrict__ stats, int B, int C, int HW, float momentum) {
+                                                    float* __restrict__ stats, int B, int C, int HW, float momentum,
+                                                    int groups) {
     __shared__ double sh[2 * BT / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int q = HW / 4, total = B * q;   // float4 units
-    float s = 0.f, ss = 0.f;
-    for (int i = tid; i < total; i += BT) {
-        const int b = i / q, p = i % q;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a + ((int64_t)b * C + c) * HW + p * 4);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-    }
-    double red[2] = {s, ss};
-    block_sum<2>(red, sh);
-    const double cnt = (double)B * HW;
-    const double mu_d = red[0] / cnt;
-    const double var = fmax(red[1] / cnt - mu_d * mu_d, 0.0);
-    const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
-    if (tid == 0) {
-        stats[c] = mu;
-        stats[C + c] = r;
-        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
-    }
+    const int q = HW / 4, total = B * q;   // float4 units of one group
     const float g = gamma[c], bt = beta[c];
-    for (int i = tid; i < total; i += BT) {
-        const int b = i / q, p = i % q;
-        const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
-        f32x4 o;
+    for (int grp = 0; grp < groups; ++grp) {     // groups are consecutive forward passes: running stats in that order
+        const float* ag = a + (int64_t)grp * B * C * HW;
+        float* hg = h + (int64_t)grp * B * C * HW;
+        float s = 0.f, ss = 0.f;
+        for (int i = tid; i < total; i += BT) {
+            const int b = i / q, p = i % q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ag + ((int64_t)b * C + c) * HW + p * 4);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        double red[2] = {s, ss};
+        block_sum<2>(red, sh);
+        const double cnt = (double)B * HW;
+        const double mu_d = red[0] / cnt;
+        const double var = fmax(red[1] / cnt - mu_d * mu_d, 0.0);
+        const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
+        if (tid == 0) {
+            stats[(grp * 2) * C + c] = mu;
+            stats[(grp * 2 + 1) * C + c] = r;
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+        for (int i = tid; i < total; i += BT) {
+            const int b = i / q, p = i % q;
+            const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ag + off);
+            f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
-        *reinterpret_cast<f32x4*>(h + off) = o;
+            for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
+            *reinterpret_cast<f32x4*>(hg + off) = o;
+        }
+        __syncthreads();      // block_sum's scratch is reused by the next group
     }
 }
 
@@ -406,45 +412,59 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
 }
 
 // Sliced BatchNorm: SB blocks per channel, each over B / SB samples; same two-launch scheme as GroupNorm.
+// Blocks are (channel, group, slice); a group is one forward pass of B samples, SB slices of B / SB samples each.
 __global__ __launch_bounds__(BT) void bn_fwd_sums(const float* __restrict__ a, double* __restrict__ ws, int B, int C,
-                                                  int HW, int SB) {
+                                                  int HW, int SB, int G) {
     __shared__ double sh[2 * BT / 64];
-    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
+    const int c = blockIdx.x / (SB * G), gs = blockIdx.x % (SB * G), grp = gs / SB, sl = gs % SB, tid = threadIdx.x;
     const int q = HW / 4, bs = B / SB, total = bs * q;
     float s = 0.f, ss = 0.f;
     for (int i = tid; i < total; i += BT) {
-        const int b = sl * bs + i / q, p = i % q;
+        const int b = grp * B + sl * bs + i / q, p = i % q;
         const f32x4 v = *reinterpret_cast<const f32x4*>(a + ((int64_t)b * C + c) * HW + p * 4);
         s += (v[0] + v[1]) + (v[2] + v[3]);
         ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     double red[2] = {s, ss};
     block_sum<2>(red, sh);
-    if (tid == 0) { ws[(c * SB + sl) * 2] = red[0]; ws[(c * SB + sl) * 2 + 1] = red[1]; }
+    if (tid == 0) { ws[(c * SB * G + gs) * 2] = red[0]; ws[(c * SB * G + gs) * 2 + 1] = red[1]; }
 }
 __global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                                    float* __restrict__ rvar, float* __restrict__ h,
                                                    float* __restrict__ stats, const double* __restrict__ ws, int B, int C,
-                                                   int HW, float momentum, int SB, int world) {
-    const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
-    double t0 = 0.0, t1 = 0.0;
-    for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
+                                                   int HW, float momentum, int SB, int world, int G) {
+    const int c = blockIdx.x / (SB * G), gs = blockIdx.x % (SB * G), grp = gs / SB, sl = gs % SB, tid = threadIdx.x;
     const double cnt = (double)B * HW * world;   // world > 1: ws holds the partial sums added over all ranks
-    const double mu_d = t0 / cnt;
-    const double var = fmax(t1 / cnt - mu_d * mu_d, 0.0);
+    auto group_stats = [&](int gi, double& mu_d, double& var) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < SB; ++k) { t0 += ws[((c * G + gi) * SB + k) * 2]; t1 += ws[((c * G + gi) * SB + k) * 2 + 1]; }
+        mu_d = t0 / cnt;
+        var = fmax(t1 / cnt - mu_d * mu_d, 0.0);
+    };
+    double mu_d, var;
+    group_stats(grp, mu_d, var);
     const float mu = (float)mu_d, r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
     if (sl == 0 && tid == 0) {
-        stats[c] = mu;
-        stats[C + c] = r;
-        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        stats[(grp * 2) * C + c] = mu;
+        stats[(grp * 2 + 1) * C + c] = r;
+    }
+    if (gs == 0 && tid == 0) {      // one thread per channel steps the running statistics through the groups in order
+        float rm = rmean[c], rv = rvar[c];
+        for (int gi = 0; gi < G; ++gi) {
+            double m, v;
+            group_stats(gi, m, v);
+            const double unbiased = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+            rm = (1.f - momentum) * rm + momentum * (float)m;
+            rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+        }
+        rmean[c] = rm;
+        rvar[c] = rv;
     }
     const float g = gamma[c], bt = beta[c];
     const int q = HW / 4, bs = B / SB, total = bs * q;
     for (int i = tid; i < total; i += BT) {
-        const int b = sl * bs + i / q, p = i % q;
+        const int b = grp * B + sl * bs + i / q, p = i % q;
         const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
         f32x4 o;
@@ -574,17 +594,23 @@ int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float*
 // ws: scratch of pgan_bn_workspace_bytes(C) bytes.
 long long pgan_bn_workspace_bytes(int C) { return (long long)C * 16 * 2 * 8; }
 
+// groups > 1: a holds `groups` consecutive forward passes of B samples each ([groups * B, C, HW]); every pass is
+// normalised with its own batch statistics (stats: [groups][2][C]) and the running statistics are stepped through
+// the passes in order, exactly as `groups` separate calls would.
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h, float* stats,
-                void* ws, long long ws_bytes, int B, int C, int HW, float momentum, hipStream_t st) {
-    if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
-    const int sb = bn_slices(B, C, HW);
-    if (sb == 1) {
-        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum);
+                void* ws, long long ws_bytes, int B, int C, int HW, float momentum, int groups, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || groups < 1) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C * groups, HW);
+    if (sb == 1 && groups == 1) {
+        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, 1);
+    } else if (sb == 1 && (long long)B * HW * groups < 8192) {
+        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, groups);
     } else {
-        if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
+        if (!ws || ws_bytes < (long long)C * sb * groups * 16) return PGAN_EINVAL;
         double* w = static_cast<double*>(ws);
-        bn_fwd_sums<<<C * sb, BT, 0, st>>>(a, w, B, C, HW, sb);
-        bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb, 1);
+        bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, w, B, C, HW, sb, groups);
+        bn_fwd_apply<<<C * sb * groups, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb, 1,
+                                                     groups);
     }
     return pgan_launch_status();
 }
@@ -608,19 +634,25 @@ int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* st
 // pgan_bn_partials(B, C, HW) doubles of partial sums, the caller adds them over the ranks, *_apply (world = number of
 // ranks, each with B samples) finishes from the totals.  dgamma / dbeta come out as 1/world of the all-rank totals.
 long long pgan_bn_partials(int B, int C, int HW) { return (long long)C * bn_slices(B, C, HW) * 2; }
+// forward with `groups` passes in one call (see pgan_bn_fwd)
+long long pgan_bn_fwd_partials(int B, int C, int HW, int groups) {
+    return groups < 1 ? -1 : (long long)C * bn_slices(B, C * groups, HW) * groups * 2;
+}
 
-int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, hipStream_t st) {
-    if (B <= 0 || C <= 0 || HW % 4 || !part) return PGAN_EINVAL;
-    const int sb = bn_slices(B, C, HW);
-    bn_fwd_sums<<<C * sb, BT, 0, st>>>(a, part, B, C, HW, sb);
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part || groups < 1) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C * groups, HW);
+    bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, part, B, C, HW, sb, groups);
     return pgan_launch_status();
 }
 
 int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
-                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, hipStream_t st) {
-    if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1) return PGAN_EINVAL;
-    const int sb = bn_slices(B, C, HW);
-    bn_fwd_apply<<<C * sb, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, part, B, C, HW, momentum, sb, world);
+                      float* stats, const double* part, int B, int C, int HW, int world, float momentum, int groups,
+                      hipStream_t st) {
+    if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1 || groups < 1) return PGAN_EINVAL;
+    const int sb = bn_slices(B, C * groups, HW);
+    bn_fwd_apply<<<C * sb * groups, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, part, B, C, HW, momentum, sb, world,
+                                                 groups);
     return pgan_launch_status();
 }
 

@@ -46,10 +46,10 @@ _SIGS = {
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
     "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P],
     "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
-    "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, P],
+    "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, I, P],
     "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
-    "pgan_bn_fwd_sums": [P, P, I, I, I, P],
-    "pgan_bn_fwd_apply": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "pgan_bn_fwd_sums": [P, P, I, I, I, I, P],
+    "pgan_bn_fwd_apply": [P, P, P, P, P, P, P, P, I, I, I, I, F, I, P],
     "pgan_bn_bwd_sums": [P, P, P, P, P, I, I, I, P],
     "pgan_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
@@ -81,7 +81,8 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
-                                "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials"])
+                                "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials",
+                                "pgan_bn_fwd_partials"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
@@ -92,6 +93,8 @@ _lib.pgan_bn_workspace_bytes.argtypes = [I]
 _lib.pgan_bn_workspace_bytes.restype = c_longlong
 _lib.pgan_bn_partials.argtypes = [I, I, I]
 _lib.pgan_bn_partials.restype = c_longlong
+_lib.pgan_bn_fwd_partials.argtypes = [I, I, I, I]
+_lib.pgan_bn_fwd_partials.restype = c_longlong
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
@@ -377,11 +380,17 @@ class HipOps:
                                  *self._gnws(), N, C, _hw(a), _stream()), "pgan_gn_bwd2")
 
     # ---------------- BatchNorm ----------------
-    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
-        B, C = a.shape[0], a.shape[1]
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1):
+        """groups > 1: a holds that many consecutive forward passes (a.shape[0] / groups samples each), stats is
+        [groups, 2, C]."""
+        B, C = a.shape[0] // groups, a.shape[1]
+        assert B * groups == a.shape[0] and stats.numel() >= groups * 2 * C
         _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
-                                self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), momentum, _stream()),
+                                self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), momentum, int(groups), _stream()),
                "pgan_bn_fwd")
+
+    def bn_fwd_partials(self, B, C, HW, groups=1) -> int:
+        return int(_lib.pgan_bn_fwd_partials(B, C, HW, int(groups)))
 
     # BatchNorm over the global batch of a data-parallel run: sums -> (caller adds `part` over the ranks) -> apply
     def bn_partials(self, B, C, HW) -> int:
@@ -393,16 +402,16 @@ class HipOps:
             raise PganError("expected a contiguous float64 CUDA tensor of bn_partials() elements")
         return part.data_ptr()
 
-    def bn_fwd_sums(self, a, part):
-        B, C = a.shape[:2]
-        _check(_lib.pgan_bn_fwd_sums(_ptr(a), self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), _stream()),
-               "pgan_bn_fwd_sums")
+    def bn_fwd_sums(self, a, part, groups=1):
+        B, C = a.shape[0] // groups, a.shape[1]
+        _check(_lib.pgan_bn_fwd_sums(_ptr(a), self._part_ptr(part, self.bn_fwd_partials(B, C, _hw(a), groups)), B, C,
+                                     _hw(a), int(groups), _stream()), "pgan_bn_fwd_sums")
 
-    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1):
-        B, C = a.shape[:2]
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1):
+        B, C = a.shape[0] // groups, a.shape[1]
         _check(_lib.pgan_bn_fwd_apply(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
-                                      self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), int(world),
-                                      momentum, _stream()), "pgan_bn_fwd_apply")
+                                      self._part_ptr(part, self.bn_fwd_partials(B, C, _hw(a), groups)), B, C, _hw(a),
+                                      int(world), momentum, int(groups), _stream()), "pgan_bn_fwd_apply")
 
     def bn_bwd_sums(self, dh, h, a, stats, part):
         B, C = a.shape[:2]

@@ -309,6 +309,40 @@ def test_batchnorm(hip, shape):
     close("bn_bwd.dbeta", db_g, db_w)
 
 
+@pytest.mark.parametrize("groups,shape", [(3, (8, 512, 4, 4)), (2, (16, 64, 32, 32)), (6, (4, 64, 4)), (3, (8, 128, 16, 16)),
+                                          (5, (64, 256, 8, 8)), (5, (64, 8, 32)), (1, (8, 128, 16, 16))])
+def test_batchnorm_forward_passes_in_one_call(hip, groups, shape):
+    """groups forward passes stacked along the batch axis: each normalised with its own statistics, running
+    statistics stepped through them in order -- as that many separate calls (fused, sliced and split entry points)."""
+    rng = np.random.default_rng(26)
+    B, C = shape[:2]
+    full = (groups * B,) + tuple(shape[1:])
+    a = rnd(rng, *full) * 0.5 + 0.2 + torch.arange(groups).repeat_interleave(B).view(-1, *([1] * (len(shape) - 1))) * 0.3
+    gamma, beta = 1 + 0.2 * rnd(rng, C), 0.2 * rnd(rng, C)
+    rm, rv = 0.1 * rnd(rng, C), 1 + 0.1 * rnd(rng, C).abs()
+    h_w, st_w = torch.zeros(full, dtype=torch.float64), torch.zeros(groups, 2, C, dtype=torch.float64)
+    rm_w, rv_w = rm.double().clone(), rv.double().clone()
+    for g in range(groups):
+        REF.bn_fwd(*d64(a[g * B:(g + 1) * B], gamma, beta), rm_w, rv_w, h_w[g * B:(g + 1) * B], st_w[g])
+    h_g, st_g = torch.zeros(full, device=DEV), torch.zeros(groups, 2, C, device=DEV)
+    rm_g, rv_g = rm.to(DEV), rv.to(DEV)
+    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g, groups=groups)
+    close("bn_groups.h", h_g, h_w)
+    close("bn_groups.stats", st_g, st_w)
+    close("bn_groups.rmean", rm_g, rm_w)
+    close("bn_groups.rvar", rv_g, rv_w)
+    hw = int(np.prod(shape[2:]))
+    part = torch.zeros(hip.bn_fwd_partials(B, C, hw, groups), dtype=torch.float64, device=DEV)
+    h_s, st_s = torch.zeros(full, device=DEV), torch.zeros(groups, 2, C, device=DEV)
+    rm_s, rv_s = rm.to(DEV), rv.to(DEV)
+    hip.bn_fwd_sums(a.to(DEV), part, groups=groups)
+    hip.bn_fwd_apply(*gpu(a, gamma, beta), rm_s, rv_s, h_s, st_s, part, 1, groups=groups)
+    close("bn_groups.split.h", h_s, h_w)
+    close("bn_groups.split.rmean", rm_s, rm_w)
+    close("bn_groups.split.rvar", rv_s, rv_w)
+    close("bn_groups.split.stats", st_s, st_w)
+
+
 @pytest.mark.parametrize("shape", [(8, 512, 4, 4), (32, 64, 32, 32), (8, 64, 4), (16, 128, 16, 16)])
 def test_batchnorm_over_two_ranks(hip, shape):
     """Split entry points: two "ranks" of B/2 samples whose partial sums are added equal one BatchNorm over B."""
@@ -323,7 +357,7 @@ def test_batchnorm_over_two_ranks(hip, shape):
     halves = [slice(0, B // 2), slice(B // 2, B)]
     ag, dhg = a.to(DEV), dh.to(DEV)
     hw = int(np.prod(shape[2:]))
-    n = hip.bn_partials(B // 2, C, hw)
+    n = max(hip.bn_partials(B // 2, C, hw), hip.bn_fwd_partials(B // 2, C, hw))
     parts = [torch.zeros(n, dtype=torch.float64, device=DEV) for _ in halves]
     for sl, part in zip(halves, parts):
         hip.bn_fwd_sums(ag[sl], part)

@@ -197,9 +197,16 @@ class TorchOps:
         """c[M,N] = a[K,M]^T @ b[K,N]."""
         c.copy_(a.t() @ b)
 
-    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1):
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1):
         """Training-mode BatchNorm + LeakyReLU.  stats[0,c]=batch mean, stats[1,c]=rstd.  Running
-        stats are updated in place (momentum, unbiased variance)."""
+        stats are updated in place (momentum, unbiased variance).  groups > 1: that many consecutive forward passes
+        stacked along the batch axis, each with its own statistics (stats [groups, 2, C])."""
+        if groups > 1:
+            B = a.shape[0] // groups
+            for g in range(groups):
+                self.bn_fwd(a[g * B:(g + 1) * B], gamma, beta, rmean, rvar, h[g * B:(g + 1) * B],
+                            stats.view(groups, 2, -1)[g], momentum)
+            return
         red = (0,) + tuple(range(2, a.dim()))
         sh = (1, -1) + (1,) * (a.dim() - 2)
         n = a.numel() // a.shape[1]
@@ -216,13 +223,27 @@ class TorchOps:
     def bn_partials(self, B, C, HW) -> int:
         return 2 * C
 
-    def bn_fwd_sums(self, a, part):
+    def bn_fwd_partials(self, B, C, HW, groups=1) -> int:
+        return 2 * C * groups
+
+    def bn_fwd_sums(self, a, part, groups=1):
+        if groups > 1:
+            B = a.shape[0] // groups
+            for g in range(groups):
+                self.bn_fwd_sums(a[g * B:(g + 1) * B], part.view(groups, -1)[g])
+            return
         red = (0,) + tuple(range(2, a.dim()))
         ad = a.double()
         part.view(-1, 2)[:, 0] = ad.sum(red)
         part.view(-1, 2)[:, 1] = (ad * ad).sum(red)
 
-    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1):
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1):
+        if groups > 1:
+            B = a.shape[0] // groups
+            for g in range(groups):
+                self.bn_fwd_apply(a[g * B:(g + 1) * B], gamma, beta, rmean, rvar, h[g * B:(g + 1) * B],
+                                  stats.view(groups, 2, -1)[g], part.view(groups, -1)[g], world, momentum)
+            return
         sh = (1, -1) + (1,) * (a.dim() - 2)
         n = world * a.numel() // a.shape[1]
         mu = part.view(-1, 2)[:, 0] / n
