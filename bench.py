@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--route", default="auto", choices=["auto", "eager", "tape", "graph"],
                     help="how an iteration is enqueued (auto: the fastest of the available ones, measured)")
     ap.add_argument("--no-graph", action="store_true", help="same as --route eager")
+    ap.add_argument("--separate-generator-forwards", action="store_true",
+                    help="one generator forward per critic step instead of the iteration's forwards batched")
     ap.add_argument("--local-bn", action="store_true",
                     help="several GPUs: BatchNorm statistics per GPU instead of over the global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,7 +190,7 @@ def main():
 
     def make_trainer(backend):
         t = FusedTrainer(backend, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
-                         seed=1234, rank=rank, world=world)
+                         seed=1234, rank=rank, world=world, batched_generator=not args.separate_generator_forwards)
         gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
         for store, shapes in ((t.eng.G, gen_param_shapes()), (t.eng.D, disc_param_shapes())):
             for k, sh in shapes.items():

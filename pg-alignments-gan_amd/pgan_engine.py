@@ -370,17 +370,30 @@ class Engine:
             self._bn_parts[key] = part
         return part
 
-    def _bn_fwd(self, key, a, gamma, beta, rmean, rvar, h, stats) -> None:
+    def _bn_fwd(self, key, a, gamma, beta, rmean, rvar, h, stats, groups: int = 1) -> None:
         """BatchNorm + LeakyReLU forward; with bn_sync set, over the global batch of all ranks (the partial sums of
-        every layer go through bn_sync, which adds them over the ranks on the current stream)."""
+        every layer go through bn_sync, which adds them over the ranks on the current stream).  groups > 1: a holds
+        that many forward passes, each with its own statistics."""
         o = self.ops
         if self.bn_sync is None:
-            o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats)
+            if groups == 1:
+                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats)
+            else:
+                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats, groups=groups)
             return
-        part = self._bn_part(("f", key), a)
-        o.bn_fwd_sums(a, part)
-        self.bn_sync(part)
-        o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world)
+        part = self._bn_parts.get(("f", key, groups))
+        if part is None:
+            hw = a.numel() // (a.shape[0] * a.shape[1])
+            n = o.bn_fwd_partials(a.shape[0] // groups, a.shape[1], hw, groups)
+            part = self._bn_parts[("f", key, groups)] = torch.zeros(n, dtype=torch.float64, device=a.device)
+        if groups == 1:
+            o.bn_fwd_sums(a, part)
+            self.bn_sync(part)
+            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world)
+        else:
+            o.bn_fwd_sums(a, part, groups=groups)
+            self.bn_sync(part)
+            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world, groups=groups)
 
     def _bn_bwd(self, key, dh, h, a, stats, gamma, da, dgamma, dbeta) -> None:
         o = self.ops
@@ -392,31 +405,70 @@ class Engine:
         self.bn_sync(part)
         o.bn_bwd_apply(dh, h, a, stats, gamma, da, dgamma, dbeta, part, self.bn_world)
 
-    def _gen_forward_2d(self, out_s: torch.Tensor) -> None:
+    def _gen_forward_2d(self, out_s: torch.Tensor, bufs=None, groups: int = 1) -> None:
+        """2-D tower on (Z, conv outputs, activations, statistics) = bufs (default: the single-pass workspace);
+        groups > 1: that many passes stacked along the batch axis."""
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
-        o.gemm_nn(self.Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), self.gA[1].view(self.B, -1))
+        Z, gA, gH, gStat = bufs if bufs is not None else (self.Z, self.gA, self.gH, self.gStat)
+        o.gemm_nn(Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), gA[1].view(Z.shape[0], -1))
         for i in range(1, 5):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
-            self._bn_fwd(n, self.gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
-                         Gb[n + ".running_var"], self.gH[i], self.gStat[i])
+            self._bn_fwd(n, gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
+                         Gb[n + ".running_var"], gH[i], gStat[i], groups)
             w = G[f"twod_conv_layers.{3 * i}.weight"]
             if i < 4:
-                o.conv_up(self.gH[i], w, self.gA[i + 1])
+                o.conv_up(gH[i], w, gA[i + 1])
             else:
-                o.conv_up(self.gH[i], w, out_s, self.act_id)
+                o.conv_up(gH[i], w, out_s, self.act_id)
 
-    def _gen_forward_1d(self, out_p: torch.Tensor) -> None:
+    def _gen_forward_1d(self, out_p: torch.Tensor, bufs=None, groups: int = 1) -> None:
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
-        o.gemm_nn(self.Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), self.hA[1].view(self.B, -1))
+        Z, hA, hH, hStat = bufs if bufs is not None else (self.Z, self.hA, self.hH, self.hStat)
+        o.gemm_nn(Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), hA[1].view(Z.shape[0], -1))
         for i in range(1, 5):
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
-            self._bn_fwd(n, self.hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
-                         Gb[n + ".running_var"], self.hH[i], self.hStat[i])
+            self._bn_fwd(n, hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
+                         Gb[n + ".running_var"], hH[i], hStat[i], groups)
             w = G[f"oned_conv_layers.{3 * i}.weight"]
             if i < 4:
-                o.convt1d_up(self.hH[i], w, self.hA[i + 1])
+                o.convt1d_up(hH[i], w, hA[i + 1])
             else:
-                o.convt1d_up(self.hH[i], w, out_p, self.act_id)
+                o.convt1d_up(hH[i], w, out_p, self.act_id)
+
+    def enable_gen_chunks(self, m: int) -> None:
+        """Generator workspace for m forward passes side by side along the batch axis (FusedTrainer: the passes of one
+        iteration share their weights, so several of them run as one launch per layer).  The single-pass buffers
+        (Z, activations, statistics, gXs / gXp) become the LAST pass's slices, so gen_forward_resident, the backward and
+        the generator step keep working on pass m - 1."""
+        B, dev = self.B, self.dev
+        f = dict(dtype=torch.float32, device=dev)
+        self.gen_chunks = m
+        self.Zw = torch.zeros(m * B, self.latent, **f)
+        self.gAw = [None] + [torch.zeros(m * B, *self.gA[i].shape[1:], **f) for i in range(1, 5)]
+        self.gHw = [None] + [torch.zeros(m * B, *self.gH[i].shape[1:], **f) for i in range(1, 5)]
+        self.gStatw = [None] + [torch.zeros(m, 2, self.gStat[i].shape[1], **f) for i in range(1, 5)]
+        self.hAw = [None] + [torch.zeros(m * B, *self.hA[i].shape[1:], **f) for i in range(1, 5)]
+        self.hHw = [None] + [torch.zeros(m * B, *self.hH[i].shape[1:], **f) for i in range(1, 5)]
+        self.hStatw = [None] + [torch.zeros(m, 2, self.hStat[i].shape[1], **f) for i in range(1, 5)]
+        self.fake_s = torch.zeros(m * B, 1, 64, 64, **f)
+        self.fake_p = torch.zeros(m * B, 1, 64, **f)
+        lo = (m - 1) * B
+        self.Z = self.Zw[lo:]
+        for i in range(1, 5):
+            self.gA[i], self.gH[i], self.gStat[i] = self.gAw[i][lo:], self.gHw[i][lo:], self.gStatw[i][m - 1]
+            self.hA[i], self.hH[i], self.hStat[i] = self.hAw[i][lo:], self.hHw[i][lo:], self.hStatw[i][m - 1]
+        self.gXs, self.gXp = self.fake_s[lo:], self.fake_p[lo:]
+
+    def gen_forward_chunks(self, c0: int, c1: int) -> None:
+        """G(z) for passes c0 .. c1-1 at once (z in Zw[c0 B : c1 B]) into fake_s / fake_p[c0 B : c1 B]: one launch per
+        layer over (c1 - c0) B samples, every pass with its own BatchNorm statistics; counts as c1 - c0 batches."""
+        B, g = self.B, c1 - c0
+        lo, hi = c0 * B, c1 * B
+        self.g_batches_tracked += g
+        sl = lambda bufs: [None] + [b[lo:hi] for b in bufs[1:]]
+        st = lambda bufs: [None] + [(b[c0] if g == 1 else b[c0:c1]) for b in bufs[1:]]
+        self._gen_forward_1d(self.fake_p[lo:hi], (self.Zw[lo:hi], sl(self.hAw), sl(self.hHw), st(self.hStatw)), g)
+        self._gen_forward_2d(self.fake_s[lo:hi], (self.Zw[lo:hi], sl(self.gAw), sl(self.gHw), st(self.gStatw)), g)
 
     def gen_backward(self, xs, xp, dxs, dxp) -> None:
         """Gradients of every generator parameter given d loss/d sites and d loss/d positions of the

@@ -25,10 +25,16 @@ from pgan_engine import Engine
 class FusedTrainer:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  critic_iter: int = 5, seed: int = 1234, lr_d: float = 5e-5, lr_g: float = 5e-5,
-                 latent: int = 128, process_group=None, rank: int = 0, world: int = 1, sync_bn: Optional[bool] = None):
-        self.ops, self.dev, self.critic_iter = ops, device, int(critic_iter)
+                 latent: int = 128, process_group=None, rank: int = 0, world: int = 1, sync_bn: Optional[bool] = None,
+                 batched_generator: bool = True):
+        self.ops, self.dev, self.critic_iter = ops, torch.device(device), int(critic_iter)
         self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g)
         self.eng.use_device_step_counters()
+        # the generator forwards of an iteration after the first (critic steps 2.., the generator step's own) share
+        # their weights and run as ONE pass over (critic_iter) x batch samples beside the first critic step
+        self.batched_generator = bool(batched_generator)
+        if self.batched_generator:
+            self.eng.enable_gen_chunks(self.critic_iter + 1)
         self.rank, self.world, self.pg = rank, world, process_group
         # data parallel: gradients are summed over the ranks before every Adam step.  The critic's largest
         # gradient (the last 2-D stage's weights, 8.4 of 11.1 MB) is complete first in the backward pass and
@@ -204,9 +210,52 @@ class FusedTrainer:
             self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
     def _iteration_body(self) -> None:
+        if self.batched_generator:
+            return self._iteration_body_batched()
         if self.sync_bn:
             return self._iteration_body_ahead()
         return self._iteration_body_one_ahead()
+
+    def _iteration_body_batched(self) -> None:
+        """The generator's weights do not change during the critic steps.  The first critic step's fakes come from a
+        forward of their own; all the others (critic steps 2.. and the generator step's own forward, whose activations
+        stay in the last slice of the workspace for its backward) are ONE forward over critic_iter x batch samples
+        -- one launch per layer, every pass with its own BatchNorm statistics, running statistics stepped in pass
+        order -- on the generator stream beside the first critic step.  z is drawn in the reference's order (the
+        device generator's stream of one long draw equals that of the separate draws)."""
+        e, o = self.eng, self.ops
+        B, gs, n = e.B, e.gside, self.critic_iter
+        m = n + 1
+        if getattr(self, "gen_done", None) is None:
+            self.gen_done = torch.cuda.Event() if self.dev.type == "cuda" else False
+        gs.fork()
+        with gs:
+            o.philox(e.Zw[:B], self.rng_z, True)
+            e.gen_forward_chunks(0, 1)
+        for i in range(n):
+            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
+            if e.loss == "gp":
+                o.philox(e.tbuf, self.rng_t, False)
+            if i == 0:
+                gs.join()
+            elif i == 1 and self.gen_done:
+                pgan_tape.call(torch.cuda.current_stream().wait_event, self.gen_done)
+            o.affine(e.fake_s[i * B:(i + 1) * B], 1.0, 0.0, e.X0[B:2 * B])      # copies
+            o.affine(e.fake_p[i * B:(i + 1) * B], 1.0, 0.0, e.P0[B:2 * B])
+            if i == 0:
+                gs.fork()
+                with gs:
+                    o.philox(e.Zw[B:m * B], self.rng_z, True)
+                    e.gen_forward_chunks(1, m)
+                    if self.gen_done:
+                        pgan_tape.call(self.gen_done.record, gs.stream)
+            e.critic_grads_resident(run_generator=False)
+            self._reduce(e.D.gflat)
+            e.adam_d()
+        gs.join()
+        e.generator_grads_resident(forward_done=True)
+        self._reduce(e.G.gflat)
+        e.adam_g()
 
     def _iteration_body_ahead(self) -> None:
         """Variant for BatchNorm statistics over several ranks: every generator forward then holds 8 small

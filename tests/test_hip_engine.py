@@ -314,3 +314,76 @@ def test_trainer_routes_agree(hip, loss):
             assert float((a[k] - b[k]).abs().max()) <= 2 * lr * 2 * n_it, (route, k)
             assert rel_err(b[k], a[k]) < 1e-3, (route, k)
         assert torch.allclose(a["run"], b["run"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "tanh"])
+def test_generator_passes_in_one_forward(hip, act):
+    """gen_forward_chunks: three forward passes as one launch per layer equal three separate forwards on the same z
+    (outputs, per-pass BatchNorm statistics, running statistics after the three, batch counter), and the last pass
+    is where the single-pass workspace points, so a backward after it works as after a forward of its own."""
+    from pgan_engine import Engine
+    B, m = 8, 3
+    engs = []
+    for chunks in (m, 0):
+        e = Engine(hip, B, DEV, act=act)
+        e.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+        e.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+        if chunks:
+            e.enable_gen_chunks(chunks)
+        engs.append(e)
+    a, b = engs
+    z = torch.randn(m * B, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    a.Zw.copy_(z)
+    a.gen_forward_chunks(0, m)
+    outs = []
+    for c in range(m):
+        b.Z.copy_(z[c * B:(c + 1) * B])
+        xs, xp = torch.zeros(B, 1, 64, 64, device=DEV), torch.zeros(B, 1, 64, device=DEV)
+        b.gen_forward_resident(xs, xp)
+        outs.append((xs, xp, [t.clone() for t in b.gStat[1:]], [t.clone() for t in b.hStat[1:]]))
+    torch.cuda.synchronize()
+    assert a.g_batches_tracked == b.g_batches_tracked == m
+    for c, (xs, xp, gst, hst) in enumerate(outs):
+        assert rel_err(a.fake_s[c * B:(c + 1) * B], xs) < 1e-5 and rel_err(a.fake_p[c * B:(c + 1) * B], xp) < 1e-5
+        for i in range(4):
+            assert torch.allclose(a.gStatw[i + 1][c], gst[i], rtol=1e-5, atol=1e-6)
+            assert torch.allclose(a.hStatw[i + 1][c], hst[i], rtol=1e-5, atol=1e-6)
+    for k, v in b.Gbuf.p.items():
+        assert torch.allclose(a.Gbuf.p[k], v, rtol=1e-5, atol=1e-6), k
+    for i in range(1, 5):       # the last pass is the single-pass workspace
+        assert rel_err(a.gH[i], b.gH[i]) < 1e-5 and rel_err(a.hH[i], b.hH[i]) < 1e-5
+    dxs, dxp = torch.randn(B, 1, 64, 64, device=DEV), torch.randn(B, 1, 64, device=DEV)
+    a.gen_backward(a.gXs, a.gXp, dxs, dxp)
+    b.gen_backward(outs[-1][0], outs[-1][1], dxs, dxp)
+    torch.cuda.synchronize()
+    assert rel_err(a.G.gflat, b.G.gflat) < 1e-5
+
+
+def test_trainer_batched_generator_equals_separate_forwards(hip):
+    """FusedTrainer with the generator forwards of an iteration batched (default) against one forward per step: same
+    z stream, losses, pool cursor, batch counter; weights equal up to rounding-noise +-lr steps."""
+    from pgan_trainer import FusedTrainer
+    B, n_it, lr = 8, 3, 5e-5
+    rs, rp = orc.synthetic_alignments(64, 9)
+    out = {}
+    for batched in (True, False):
+        tr = FusedTrainer(hip, B, DEV, critic_iter=3, seed=78, batched_generator=batched)
+        tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+        tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+        tr.weights_changed()
+        tr.set_pool(rs, rp)
+        for _ in range(n_it):
+            tr.iteration()
+        torch.cuda.synchronize()
+        out[batched] = dict(d=tr.eng.D.flat.clone(), g=tr.eng.G.flat.clone(), losses=tr.losses(), cursor=int(tr.cursor),
+                            rng=tr.rng_z.clone(), nb=tr.eng.g_batches_tracked, z=tr.eng.Z.clone(),
+                            run={k: v.clone() for k, v in tr.eng.Gbuf.p.items()})
+    a, b = out[True], out[False]
+    assert a["cursor"] == b["cursor"] and torch.equal(a["rng"], b["rng"]) and a["nb"] == b["nb"]
+    assert torch.equal(a["z"], b["z"])                  # the generator step's z: same draw either way
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (a["losses"], b["losses"])
+    for k in ("d", "g"):
+        assert float((a[k] - b[k]).abs().max()) <= 2 * lr * 3 * n_it and rel_err(a[k], b[k]) < 1e-3, k
+    for k in a["run"]:
+        assert torch.allclose(a["run"][k], b["run"][k], rtol=1e-3, atol=1e-5), k
