@@ -232,8 +232,13 @@ def main():
     if args.route in ("auto", "eager"):
         routes["eager"] = tr.iteration
     if args.route in ("auto", "tape"):
-        tr.record_tape()
-        routes["tape"] = tr.replay_tape
+        try:
+            tr.record_tape()
+            routes["tape"] = tr.replay_tape
+        except RuntimeError as ex:            # op backend without tape support: the eager route remains
+            if args.route == "tape":
+                raise
+            print(f"launch tape unavailable: {ex}", file=sys.stderr)
     if args.route in ("auto", "graph") and world == 1 and pg is None:
         tr.capture()
         routes["graph"] = tr.replay
