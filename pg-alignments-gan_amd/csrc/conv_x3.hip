@@ -707,8 +707,9 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
     if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     const uint16_t* up = WP + (size_t)3 * Cs * Cl * 16;
-    // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU
-    int variant = g_up_variant ? g_up_variant : ((Cl / 32) * PixTile<HS, 64>::ntiles(N) < 512 ? 5 : 1);
+    // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU, and always at hs = 4 (measured
+    // 135 against 149 us at N = 320; the 64-pixel tile spills there unless its occupancy drops to 2 waves per SIMD)
+    int variant = g_up_variant ? g_up_variant : ((HS == 4 || (Cl / 32) * PixTile<HS, 64>::ntiles(N) < 512) ? 5 : 1);
     if ((variant == 3 || variant == 4) && Cl % 64) variant -= 2;
     const int nc = (variant == 3 || variant == 4) ? 2 : 1, bn = variant == 5 ? 32 : ((variant & 1) ? 64 : 128);
     const int blocks = (Cl / (32 * nc)) * (bn == 128 ? PixTile<HS, 128>::ntiles(N)
