@@ -63,7 +63,8 @@ int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs,
 long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
                        int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
-/* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant"; 0 = by size) */
+/* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant", "up_ks", "up_order",
+ * "wg_target" = blocks the weight-gradient split aims at; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
 
 /* up to 4 such reductions in one launch (the norm-parameter gradients of the four stages) */

@@ -642,11 +642,13 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restric
     *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
 }
 
+int g_wg_target = 512;   // tuning override: "wg_target"
+
 template <int HS>
 int wgrad_x3_splits(int N, int Cs, int Cl) {
     const int tiles = (Cs / 64) * (Cl / 8);
     const int chunks = PixTile<HS, 64>::ntiles(N);
-    int want = (512 + tiles - 1) / tiles;        // ~2 blocks per CU
+    int want = (g_wg_target + tiles - 1) / tiles;        // blocks aimed at (512: 2 per CU)
     if (want > chunks) want = chunks;
     if (want < 1) want = 1;
     const int cpb = (chunks + want - 1) / want;
@@ -741,6 +743,7 @@ int pgan_x3_set_option(const char* name, int value) {
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
     if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_order") && value >= 0 && value <= 2) { g_up_order = value; return PGAN_OK; }
+    if (eq(name, "wg_target") && (value == 0 || (value >= 64 && value <= 4096))) { g_wg_target = value ? value : 512; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }

@@ -76,6 +76,16 @@ for N in tuple(int(v) for v in os.environ.get('CB_N', '64,192').split(',')):
                 us = timeit(lambda: ops.conv_up(y, w, xx))
                 print(f"up   N={N:3d} hs={hs:2d} x3 v={var} ks={ks}:     {us:8.1f} us {fl/us/1e6:7.1f} TF  relerr {err:.2e}")
             set_x3_option("up_variant", 0); set_x3_option("up_order", 0)
+        if which in ("wgt",):
+            from pgan_hip import set_x3_option
+            for tgt in (256, 384, 512, 768, 1024, 1536):
+                set_x3_option("wg_target", tgt)
+                try:
+                    us = timeit(lambda: ops.conv_wgrad(y, x, dw))
+                    print(f"wgrd N={N:3d} hs={hs:2d} target={tgt}: {us:8.1f} us {fl/us/1e6:7.1f} TF")
+                except Exception as ex:
+                    print(f"wgrd N={N:3d} hs={hs:2d} target={tgt}: {ex}")
+            set_x3_option("wg_target", 0)
         if which in ("wg3",):
             ref = None
             for px in (False, True):
