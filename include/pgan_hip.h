@@ -4,7 +4,8 @@
  * Conventions for every entry point: plain device pointers and sizes, fp32 tensors contiguous in
  * NCHW / NCL order, work is only ENQUEUED on the caller's hipStream_t (no synchronisation, no
  * allocation, no host reads), scratch comes from the caller, return 0 on success, -1 for an
- * unsupported shape or argument (nothing was launched), -2 if HIP reported a launch error.
+ * unsupported shape or argument (nothing was launched), -2 if HIP reported a launch error, -3 for a
+ * size beyond the fixed maximum of pgan_gn_fwd_static.
  *
  * The reference has no native boundary (it is pure PyTorch); each entry point replaces the ATen
  * op(s) that the cited reference line dispatches to.  Paths are relative to /root/reference.
@@ -78,6 +79,14 @@ int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const
 long long pgan_gn_workspace_bytes(int N);
 int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
                 long long ws_bytes, int N, int C, int HW, hipStream_t st);
+/* pgan_gn_fwd for callers that cannot allocate device memory or bring a workspace (code under hipGraph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result as pgan_gn_fwd; the
+ * slice partial sums live in a fixed array inside the library (384 KiB per GPU, for up to
+ * pgan_gn_fwd_static_max_samples() = 2048 samples per call; more returns -3 and launches nothing).  Calls no hipMalloc /
+ * hipFree.  All calls on one GPU share that array: calls that overlap there (different streams) race. */
+int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C,
+                       int HW, hipStream_t st);
+int pgan_gn_fwd_static_max_samples(void);
 /* first-order backward (autograd through GroupNorm/LeakyReLU): d = dL/da from u = dL/dh;
  * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta. */
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,

@@ -10,6 +10,8 @@
 // the Jacobian d xh / d a and (being symmetric) its transpose.
 #include "pgan_common.h"
 
+#include <atomic>
+
 namespace {
 
 
@@ -544,6 +546,13 @@ bool gn_shape_ok(int N, int C, int HW, const void* ws, long long ws_bytes) {
            ws != nullptr && ws_bytes >= (long long)N * SL * 3 * 8;
 }
 
+// pgan_gn_fwd_static: slice partial sums of up to GN_STATIC_MAX_N samples (384 KiB per GPU, held until the process
+// ends).  In host code the array's name only stands for the symbol; g_scratch_ptr[device] is its device address.
+constexpr int GN_STATIC_MAX_N = 2048;
+constexpr int MAX_DEVICES = 64;
+static __device__ __align__(256) double scratch[GN_STATIC_MAX_N * SL * 3];
+std::atomic<double*> g_scratch_ptr[MAX_DEVICES];
+
 }  // namespace
 
 extern "C" {
@@ -560,6 +569,31 @@ int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h,
     gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C);
     return pgan_launch_status();
 }
+
+// The same operation for callers that cannot allocate (code under graph capture, serving loops, harnesses that forbid
+// hipMalloc): the slice partial sums live in `scratch`, a fixed array inside the library's code object, instead of a
+// caller workspace.  Each GPU holds its own copy of the array at its own address: the address is looked up once per
+// device, with that device current, and kept.  Every partial sum that the apply launch reads is written by the sums
+// launch of the same call, so nothing needs clearing between calls; two calls that overlap on one GPU (different
+// streams) share the array and race.
+int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C,
+                       int HW, hipStream_t st) {
+    if (N > GN_STATIC_MAX_N) return PGAN_ELIMIT;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return PGAN_ELAUNCH;
+    double* w = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!w) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PGAN_ELAUNCH;
+        w = static_cast<double*>(p);
+        g_scratch_ptr[dev].store(w, std::memory_order_release);
+    }
+    if (!gn_shape_ok(N, C, HW, w, (long long)sizeof(double) * GN_STATIC_MAX_N * SL * 3)) return PGAN_EINVAL;
+    gn_fwd_sums<<<N * SL, ST, 0, st>>>(a, w, C * HW, C);
+    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C);
+    return pgan_launch_status();
+}
+int pgan_gn_fwd_static_max_samples(void) { return GN_STATIC_MAX_N; }
 
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
                 float* stats_b, float* pg, float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW,

@@ -6,6 +6,7 @@
 #define PGAN_OK 0
 #define PGAN_EINVAL (-1)   // unsupported shape / bad argument
 #define PGAN_ELAUNCH (-2)  // HIP reported a launch error
+#define PGAN_ELIMIT (-3)   // size beyond the fixed maximum of an entry point that allocates nothing
 
 #define PGAN_SLOPE 0.1f
 #define PGAN_EPS 1e-5f

@@ -74,6 +74,7 @@ _SIGS = {
     "pgan_parse_alignments": [P, P, I, P, P, P, I],
     "pgan_unpack_sites": [P, P, L, F, F, P],
     "pgan_pack_sites": [P, P, L, P],
+    "pgan_gn_fwd_static": [P, P, P, P, P, I, I, I, P],
     "pgan_step_graph_begin": [P],
     "pgan_step_graph_end": [P, ctypes.POINTER(ctypes.c_void_p)],
     "pgan_step_graph_launch": [P, P],
@@ -82,7 +83,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
                                 "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials",
-                                "pgan_bn_fwd_partials"])
+                                "pgan_bn_fwd_partials", "pgan_gn_fwd_static_max_samples"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
@@ -95,6 +96,8 @@ _lib.pgan_bn_partials.argtypes = [I, I, I]
 _lib.pgan_bn_partials.restype = c_longlong
 _lib.pgan_bn_fwd_partials.argtypes = [I, I, I, I]
 _lib.pgan_bn_fwd_partials.restype = c_longlong
+_lib.pgan_gn_fwd_static_max_samples.argtypes = []
+_lib.pgan_gn_fwd_static_max_samples.restype = c_int
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
@@ -207,7 +210,8 @@ class StepGraph:
 
 def _check(rc: int, what: str):
     if rc != 0:
-        raise PganError(f"{what} failed with code {rc} ({'bad shape/argument' if rc == -1 else 'HIP launch error'})")
+        why = {-1: "bad shape/argument", -2: "HIP launch error", -3: "size beyond the entry point's fixed maximum"}
+        raise PganError(f"{what} failed with code {rc} ({why.get(rc, 'unknown')})")
 
 
 def _hw(t: torch.Tensor) -> int:
@@ -361,6 +365,12 @@ class HipOps:
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
                                 _stream()), "pgan_gn_fwd")
+
+    def gn_fwd_static(self, a, gamma, beta, h, stats):
+        """gn_fwd with the partial sums in the library's own fixed array (nothing allocated, no workspace)."""
+        N, C = a.shape[0], a.shape[1]
+        _check(_lib.pgan_gn_fwd_static(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), N, C, _hw(a), _stream()),
+               "pgan_gn_fwd_static")
 
     def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
         N, C = a.shape[0], a.shape[1]

@@ -1,0 +1,64 @@
+"""pgan_gn_fwd_static, the entry point that allocates nothing (partial sums in a fixed array inside the library),
+against pgan_gn_fwd (caller workspace), through the C-ABI: bit-identical outputs on two calls in a row, the second
+with a smaller input; sizes beyond the fixed maximum are refused before anything is launched."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _call(lib, name, a, gamma, beta, ws=None):
+    N, C, HW = a.shape[0], a.shape[1], a.shape[2] * a.shape[3]
+    h, st = torch.full_like(a, -7.0), torch.full((N, 2), -7.0, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    if ws is None:
+        rc = lib.pgan_gn_fwd_static(a.data_ptr(), gamma.data_ptr(), beta.data_ptr(), h.data_ptr(), st.data_ptr(), N, C,
+                                    HW, stream)
+    else:
+        rc = lib.pgan_gn_fwd(a.data_ptr(), gamma.data_ptr(), beta.data_ptr(), h.data_ptr(), st.data_ptr(),
+                             ws.data_ptr(), ws.numel(), N, C, HW, stream)
+    assert rc == 0, (name, rc)
+    torch.cuda.synchronize()
+    return h, st
+
+
+def test_static_scratch_groupnorm_equals_workspace_groupnorm():
+    from pgan_hip import _lib
+    lib = _lib._real
+    nmax = lib.pgan_gn_fwd_static_max_samples()
+    assert nmax == 2048
+    ws = torch.empty(lib.pgan_gn_workspace_bytes(nmax), dtype=torch.uint8, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    # two calls in a row on the same GPU, the second smaller (the array keeps the first call's partial sums)
+    for N, C, hs in ((192, 128, 16), (5, 512, 4), (64, 64, 32), (3, 256, 8)):
+        a = (torch.randn(N, C, hs, hs, generator=g) * 2 + 0.3).to(DEV)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        before = torch.cuda.memory_stats(DEV).get("allocation.all.allocated", 0)
+        h1, s1 = _call(lib, "static", a, gamma, beta)
+        h2, s2 = _call(lib, "workspace", a, gamma, beta, ws)
+        assert torch.equal(h1, h2) and torch.equal(s1, s2), (N, C, hs)
+        assert not bool((h1 == -7.0).all())
+        # reference statement of the op in fp64
+        x = a.double().view(N, -1)
+        mu, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+        y = ((x - mu) / (var + 1e-5).sqrt()).view(N, C, -1) * gamma.double().view(1, C, 1) + beta.double().view(1, C, 1)
+        want = torch.where(y > 0, y, 0.1 * y).view_as(a)
+        assert float((h1.double() - want).norm() / want.norm()) < 1e-6
+        del before
+    # beyond the maximum: refused (-3), nothing written
+    big = torch.zeros(nmax + 1, 8, 4, 4, device=DEV)
+    h = torch.full_like(big, -7.0)
+    st = torch.full((nmax + 1, 2), -7.0, device=DEV)
+    one = torch.ones(8, device=DEV)
+    rc = lib.pgan_gn_fwd_static(big.data_ptr(), one.data_ptr(), one.data_ptr(), h.data_ptr(), st.data_ptr(), nmax + 1, 8,
+                                16, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == -3 and bool((h == -7.0).all())
+    # at the maximum it runs
+    rc = lib.pgan_gn_fwd_static(big.data_ptr(), one.data_ptr(), one.data_ptr(), h.data_ptr(), st.data_ptr(), nmax, 8,
+                                16, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0 and bool((h[:nmax] == 1.0).all()) and bool((h[nmax:] == -7.0).all())
