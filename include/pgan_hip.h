@@ -203,6 +203,25 @@ int pgan_parse_alignments(const char* const* sites_paths, const char* const* pos
 int pgan_unpack_sites(const unsigned char* bits, float* sites, long long n, float scale, float shift, hipStream_t st);
 int pgan_pack_sites(const float* sites, unsigned char* bits, long long n, hipStream_t st);
 
+/* Text output of Hudson's ms, as SimulatorGenerator.get_batch reads it from the subprocess (src/train_wgan_v2.py:342-344),
+ * parsed on the host the way read_ms_data does (src/train_wgan_v2.py:311-330; the last replicate of the text is
+ * dropped): sites[r][rows][cols], pos[r][cols].  Returns the replicates written (<= max_reps), -1 bad arguments,
+ * -3 a replicate that is not rows x cols, -4 a genotype character that is not a digit. */
+int pgan_parse_ms(const char* text, long long len, int rows, int cols, int max_reps, float* sites, float* pos);
+
+/* ---- device-side sampling around the step (Philox state as pgan_philox).
+ * pgan_fakebuf_step: FakeBuffer.add then FakeBuffer.sample (src/train_wgan_v2.py:98-117) on a ring of `size` (<= 16320)
+ * alignments resident in HBM: appends the B new alignments (oldest overwritten), then writes B alignments drawn without
+ * replacement to out_s / out_p.  state: 4 device ints (head, count, error flag, spare), zeroed by the caller once;
+ * slots: B device ints of scratch; picks: NULL, or B device ints with the logical indices to take (0 = oldest) in
+ * place of random draws (state[2] is set if one lies outside the buffer).
+ * pgan_sample_genotypes: sample_genotypes_bernoulli (src/train_wgan_v2.py:162-192) on p[n][1][64][S]. */
+int pgan_fakebuf_step(float* buf_s, float* buf_p, int size, int* state, int* slots, const float* new_s,
+                      const float* new_p, float* out_s, float* out_p, int B, int Ms, int Mp, unsigned int* rng,
+                      const int* picks, hipStream_t st);
+int pgan_sample_genotypes(const float* p, float* out, long long n, int S, unsigned int* rng, int require_variation,
+                          hipStream_t st);
+
 /* ---- one step as a hipGraph (the reference launches its step op by op from Python, src/train_wgan_v2.py:534-634):
  * begin capture on st, enqueue the step once through the entry points above (side streams join st through events),
  * end -> executable graph; launch replays it on st; destroy frees it.  No kernel runs between begin and end. */

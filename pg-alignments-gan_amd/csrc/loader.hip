@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -140,6 +141,73 @@ int pgan_parse_alignments(const char* const* sites_paths, const char* const* pos
     work();
     for (auto& t : pool) t.join();
     return failed.load();
+}
+
+// Host side.  Text output of Hudson's `ms` (what SimulatorGenerator.get_batch reads from the subprocess,
+// src/train_wgan_v2.py:342-344) -> sites[r][rows][cols] (0 / 1 as fp32) and pos[r][cols], following read_ms_data
+// (src/train_wgan_v2.py:311-330) line for line: the text is split at '\n'; a replicate starts at every line that
+// contains "//"; its third line is "positions: ..." split at single spaces with the first and the LAST token dropped
+// (ms ends that line with a space) and empty tokens skipped; the lines after it up to, not including, the last line
+// before the next "//" are one individual each, one digit per site; the LAST replicate of the text is dropped (the
+// caller asks ms for one more than it needs).  Returns the number of replicates written (<= max_reps), or
+// -1 bad arguments, -3 a replicate with other than rows x cols genotypes or cols positions, -4 a non-digit genotype.
+int pgan_parse_ms(const char* text, long long len, int rows, int cols, int max_reps, float* sites, float* pos) {
+    if (!text || len < 0 || rows <= 0 || cols <= 0 || max_reps < 0 || !sites || !pos) return PGAN_EINVAL;
+    std::vector<std::pair<const char*, const char*>> lines;      // [begin, end) of every '\n'-separated piece
+    const char* b = text;
+    const char* const fin = text + len;
+    for (const char* p = text;; ++p) {
+        if (p == fin || *p == '\n') {
+            lines.emplace_back(b, p);
+            if (p == fin) break;
+            b = p + 1;
+        }
+    }
+    std::vector<size_t> starts;
+    for (size_t i = 0; i < lines.size(); ++i) {
+        for (const char* p = lines[i].first; p + 1 < lines[i].second; ++p)
+            if (p[0] == '/' && p[1] == '/') { starts.push_back(i); break; }
+    }
+    if (starts.empty()) return 0;
+    starts.push_back(lines.size());
+    int nrep = 0;
+    for (size_t k = 0; k + 2 < starts.size() && nrep < max_reps; ++k, ++nrep) {      // all chunks but the last
+        const size_t l0 = starts[k], l1 = starts[k + 1];
+        if (l1 < l0 + 4) return -3;
+        // positions: tokens between single spaces, first and last dropped, empty ones skipped
+        std::vector<std::pair<const char*, const char*>> tok;
+        const char* tb = lines[l0 + 2].first;
+        const char* const te = lines[l0 + 2].second;
+        for (const char* p = tb;; ++p) {
+            if (p == te || *p == ' ') {
+                tok.emplace_back(tb, p);
+                if (p == te) break;
+                tb = p + 1;
+            }
+        }
+        int np = 0;
+        for (size_t t = 1; t + 1 < tok.size(); ++t) {
+            if (tok[t].first == tok[t].second) continue;
+            if (np >= cols) return -3;
+            const std::string v(tok[t].first, tok[t].second);
+            char* end;
+            const double d = std::strtod(v.c_str(), &end);
+            if (end == v.c_str()) return -3;
+            pos[(size_t)nrep * cols + np++] = (float)d;
+        }
+        if (np != cols) return -3;
+        if ((long long)(l1 - 1) - (long long)(l0 + 3) != rows) return -3;
+        for (int r = 0; r < rows; ++r) {
+            const auto& ln = lines[l0 + 3 + r];
+            if (ln.second - ln.first != cols) return -3;
+            for (int c = 0; c < cols; ++c) {
+                const char ch = ln.first[c];
+                if (ch < '0' || ch > '9') return -4;
+                sites[((size_t)nrep * rows + r) * cols + c] = (float)(ch - '0');
+            }
+        }
+    }
+    return nrep;
 }
 
 // Device side: sites[n][1][64][64] (fp32) = scale * bit + shift from bits[n][512].

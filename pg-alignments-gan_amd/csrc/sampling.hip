@@ -1,0 +1,189 @@
+// Device-side random sampling steps around the training step, all driven by the same Philox4x32-10 state words as
+// pgan_philox (state[0..1] seed, state[2..3] 64-bit offset in units of one Philox call = 4 outputs):
+//   * replay buffer of generated alignments (FakeBuffer, src/train_wgan_v2.py:98-117): bounded FIFO + a batch drawn
+//     from it without replacement, as three tiny launches so that the critic step that uses it stays inside a
+//     recorded launch tape / hipGraph (no host random numbers, no host integers);
+//   * genotype sampling of generated alignments (sample_genotypes_bernoulli, src/train_wgan_v2.py:162-192).
+#include "pgan_common.h"
+
+namespace {
+
+__device__ __forceinline__ void philox4(uint64_t ctr, uint32_t k0, uint32_t k1, uint32_t (&c)[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = 0u; c[3] = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ uint64_t philox_offset(const uint32_t* state) { return ((uint64_t)state[3] << 32) | state[2]; }
+__device__ __forceinline__ void philox_bump(uint32_t* state, uint64_t calls) {
+    const uint64_t off = philox_offset(state) + calls;
+    state[2] = (uint32_t)off;
+    state[3] = (uint32_t)(off >> 32);
+}
+
+// ---------------- replay buffer ----------------
+// ring state: st[0] = head (next slot to overwrite), st[1] = count (valid alignments, <= size).
+// Logical index u (0 = oldest, count - 1 = newest: the order of the reference's deque) lives in physical slot
+// (head - count + u) mod size.
+
+// append: new alignment b goes to slot (head + b) mod size.  Reads the state only.
+__global__ void fakebuf_append_kernel(float* __restrict__ buf_s, float* __restrict__ buf_p,
+                                      const float* __restrict__ new_s, const float* __restrict__ new_p,
+                                      const int* __restrict__ st, int size, int B, int Ms, int Mp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int head = st[0];
+    if (i < (int64_t)B * Ms / 4) {
+        const int b = (int)(i / (Ms / 4)), e = (int)(i % (Ms / 4));
+        reinterpret_cast<f32x4*>(buf_s + (int64_t)((head + b) % size) * Ms)[e] = reinterpret_cast<const f32x4*>(new_s)[i];
+    }
+    if (i < (int64_t)B * Mp / 4) {
+        const int b = (int)(i / (Mp / 4)), e = (int)(i % (Mp / 4));
+        reinterpret_cast<f32x4*>(buf_p + (int64_t)((head + b) % size) * Mp)[e] = reinterpret_cast<const f32x4*>(new_p)[i];
+    }
+}
+
+// draw: one block.  Advances the ring state by the B alignments just appended, then picks B distinct logical indices
+// in [0, count) -- a partial Fisher-Yates shuffle of 0..count-1 held in LDS, one 32-bit Philox word per pick (or the
+// caller's indices, for tests) -- and writes their physical slots.  picks_in: B logical indices or null.
+__global__ __launch_bounds__(256) void fakebuf_draw_kernel(int* __restrict__ st, int* __restrict__ slots,
+                                                          const int* __restrict__ picks_in, uint32_t* __restrict__ rng,
+                                                          int size, int B) {
+    extern __shared__ int perm[];
+    __shared__ int bad;
+    const int head = (st[0] + B) % size;
+    const int count = min(size, st[1] + B);
+    if (threadIdx.x == 0) bad = 0;
+    for (int i = threadIdx.x; i < count; i += 256) perm[i] = i;
+    __syncthreads();
+    if (picks_in) {
+        for (int k = threadIdx.x; k < B; k += 256) {
+            const int u = picks_in[k];
+            if (u < 0 || u >= count) bad = 1;
+            slots[k] = ((head - count + (u < 0 ? 0 : u % count)) % size + size) % size;
+        }
+    } else if (threadIdx.x == 0) {
+        const uint64_t off = philox_offset(rng);
+        uint32_t c[4];
+        for (int k = 0; k < B; ++k) {
+            if ((k & 3) == 0) philox4(off + (uint64_t)(k >> 2), rng[0], rng[1], c);
+            const int j = k + (int)__umulhi(c[k & 3], (uint32_t)(count - k));
+            const int v = perm[j];
+            perm[j] = perm[k];
+            perm[k] = v;
+            slots[k] = ((head - count + v) % size + size) % size;
+        }
+        philox_bump(rng, (uint64_t)((B + 3) / 4));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st[0] = head;
+        st[1] = count;
+        st[2] |= bad;          // sticky error flag: an injected index outside the buffer
+    }
+}
+
+__global__ void fakebuf_gather_kernel(const float* __restrict__ buf_s, const float* __restrict__ buf_p,
+                                      const int* __restrict__ slots, float* __restrict__ out_s,
+                                      float* __restrict__ out_p, int B, int Ms, int Mp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)B * Ms / 4) {
+        const int b = (int)(i / (Ms / 4)), e = (int)(i % (Ms / 4));
+        reinterpret_cast<f32x4*>(out_s)[i] = reinterpret_cast<const f32x4*>(buf_s + (int64_t)slots[b] * Ms)[e];
+    }
+    if (i < (int64_t)B * Mp / 4) {
+        const int b = (int)(i / (Mp / 4)), e = (int)(i % (Mp / 4));
+        reinterpret_cast<f32x4*>(out_p)[i] = reinterpret_cast<const f32x4*>(buf_p + (int64_t)slots[b] * Mp)[e];
+    }
+}
+
+// ---------------- genotype sampling ----------------
+// One thread per (alignment, column): 64 Bernoulli draws down the column (u < p, as torch.bernoulli); a column that
+// came out monomorphic is drawn again and one individual, picked in proportion to its probability of carrying the
+// missing allele (+1e-7), is set to it.  CALLS Philox calls are reserved per column (64 + 64 + 1 uniforms).
+constexpr int GT_ROWS = 64, GT_CALLS = 36;
+
+__global__ __launch_bounds__(256) void sample_genotypes_kernel(const float* __restrict__ p, float* __restrict__ out,
+                                                               int64_t ncol, int S, const uint32_t* __restrict__ rng,
+                                                               int require_variation) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ncol) return;
+    const int64_t n = t / S;
+    const int j = (int)(t % S);
+    const float* col = p + n * GT_ROWS * S + j;
+    float* ocol = out + n * GT_ROWS * S + j;
+    const uint64_t base = philox_offset(rng) + (uint64_t)t * GT_CALLS;
+    const uint32_t k0 = rng[0], k1 = rng[1];
+    uint32_t c[4];
+    auto draw_column = [&](int call0) {
+        uint64_t m = 0;
+        for (int i = 0; i < GT_ROWS; ++i) {
+            if ((i & 3) == 0) philox4(base + call0 + (i >> 2), k0, k1, c);
+            const float u = (c[i & 3] >> 8) * (1.0f / 16777216.0f);
+            if (u < col[(int64_t)i * S]) m |= 1ull << i;
+        }
+        return m;
+    };
+    uint64_t m = draw_column(0);
+    if (require_variation && (m == 0ull || m == ~0ull)) {
+        const bool have = m != 0ull;                       // the allele every individual carries
+        double total = 0.0;
+        for (int i = 0; i < GT_ROWS; ++i) {
+            const float q = col[(int64_t)i * S];
+            total += (double)(have ? 1.f - q : q) + 1e-7;
+        }
+        m = draw_column(16);
+        philox4(base + 32, k0, k1, c);
+        const double target = (double)((c[0] >> 8) * (1.0f / 16777216.0f)) * total;
+        double acc = 0.0;
+        int pick = GT_ROWS - 1;
+        for (int i = 0; i < GT_ROWS; ++i) {
+            const float q = col[(int64_t)i * S];
+            acc += (double)(have ? 1.f - q : q) + 1e-7;
+            if (target < acc) { pick = i; break; }
+        }
+        if (have) m &= ~(1ull << pick);
+        else m |= 1ull << pick;
+    }
+    for (int i = 0; i < GT_ROWS; ++i) ocol[(int64_t)i * S] = (float)((m >> i) & 1ull);
+}
+__global__ void genotype_rng_advance_kernel(uint32_t* rng, uint64_t calls) { philox_bump(rng, calls); }
+
+}  // namespace
+
+extern "C" {
+
+// One replay-buffer step: append the B alignments new_s / new_p (Ms / Mp floats each) to the ring buf_s / buf_p
+// (`size` <= 16320 slots), then write B alignments drawn from the buffer without replacement to out_s / out_p.
+// state: 4 device ints (head, count, error flag, unused), zero at the start; slots: B device ints of scratch;
+// rng: Philox state as pgan_philox; picks: null, or B device ints = logical indices (0 oldest) used instead of
+// random draws (state[2] becomes 1 if one lies outside the buffer).
+int pgan_fakebuf_step(float* buf_s, float* buf_p, int size, int* state, int* slots, const float* new_s,
+                      const float* new_p, float* out_s, float* out_p, int B, int Ms, int Mp, unsigned int* rng,
+                      const int* picks, hipStream_t st) {
+    if (B <= 0 || size < B || size > 16320 || Ms % 4 || Mp % 4 || Mp > Ms || !state || !slots || (!rng && !picks))
+        return PGAN_EINVAL;
+    const int grid = (int)(((int64_t)B * Ms / 4 + 255) / 256);
+    fakebuf_append_kernel<<<grid, 256, 0, st>>>(buf_s, buf_p, new_s, new_p, state, size, B, Ms, Mp);
+    fakebuf_draw_kernel<<<1, 256, (size_t)size * sizeof(int), st>>>(state, slots, picks, rng, size, B);
+    fakebuf_gather_kernel<<<grid, 256, 0, st>>>(buf_s, buf_p, slots, out_s, out_p, B, Ms, Mp);
+    return pgan_launch_status();
+}
+
+// out[n][1][64][S] ~ Bernoulli(p) with every column polymorphic when require_variation != 0 (see the kernel).
+int pgan_sample_genotypes(const float* p, float* out, long long n, int S, unsigned int* rng, int require_variation,
+                          hipStream_t st) {
+    if (n <= 0 || S <= 0 || !p || !out || !rng) return PGAN_EINVAL;
+    const int64_t ncol = (int64_t)n * S;
+    sample_genotypes_kernel<<<(unsigned)((ncol + 255) / 256), 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
+    genotype_rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)ncol * GT_CALLS);
+    return pgan_launch_status();
+}
+
+}  // extern "C"

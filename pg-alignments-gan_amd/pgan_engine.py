@@ -177,7 +177,9 @@ class Engine:
                  latent: int = LATENT, lr_d: float = 5e-5, lr_g: float = 5e-5,
                  betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8,
                  g_store: Optional["FlatStore"] = None, g_buffers: Optional["FlatStore"] = None,
-                 d_store: Optional["FlatStore"] = None):
+                 d_store: Optional["FlatStore"] = None, generator_only: bool = False):
+        """generator_only: no discriminator workspace (an engine that only runs generator forwards / backwards, e.g.
+        the 1000-sample plotting forward of the trainer)."""
         if loss not in ("gp", "div"):
             raise ValueError(f"loss must be 'gp' or 'div', got {loss!r}")
         if act not in ("sigmoid", "tanh"):
@@ -225,11 +227,19 @@ class Engine:
         self.side = SideStream(device)
         self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
         self.gside = SideStream(device)     # generator forwards made one critic step ahead (FusedTrainer)
+        if hasattr(ops, "reserve_stream"):  # per-stream norm scratch exists before anything runs there
+            for s in (self.side, self.wside, self.gside):
+                if s.enabled:
+                    ops.reserve_stream(s.stream.cuda_stream)
         # called with a parameter name right after that discriminator weight gradient has been enqueued (on
         # the stream it was enqueued on): lets a data-parallel driver start reducing it during the backward
         self.grad_ready = None
 
         NT = self.NT
+        self.generator_only = bool(generator_only)
+        NPl = self.NP
+        if generator_only:
+            NT = B = NPl = 0        # zero-sized discriminator buffers
         # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
         self.X0 = torch.zeros(NT, 1, 64, 64, **f)        # sites: primal slots then v (tangent input)
         self.P0 = torch.zeros(2 * B, 1, 64, **f)         # positions of real | fake
@@ -244,22 +254,24 @@ class Engine:
         self.dPGB = [None] + [torch.zeros(NT, 2 * D2_CH[k], **f) for k in range(1, 5)]
         self.dPG = [None] + [self.dPGB[k][:, :D2_CH[k]] for k in range(1, 5)]
         self.dPB = [None] + [self.dPGB[k][:, D2_CH[k]:] for k in range(1, 5)]
-        self.G0 = torch.zeros(max(self.NP, B), 1, 64, 64, **f)   # input gradient of penalised samples / gen step
+        self.G0 = torch.zeros(max(NPl, B), 1, 64, 64, **f)   # input gradient of penalised samples / gen step
         self.d1A = [torch.zeros(2 * B, D1_CH[i + 1], D1_LEN[i + 1], **f) for i in range(3)]
         self.F1 = torch.zeros(2 * B, FEAT1, **f)
         self.dP0 = torch.zeros(B, 1, 64, **f)            # d loss / d positions (generator step)
         self.score = torch.zeros(2 * B, **f)
         self.coef = torch.zeros(NT, **f)                 # per-slot seed / head-gradient weights
         self.coef_head = torch.zeros(NT, **f)
-        self.coef_top = torch.zeros(self.NP, **f)        # div: Wasserstein seed of the penalised samples
-        self.HB4 = torch.zeros(self.NP, 512, 4, 4, **f)  # div: primal adjoint entering the top stage
+        self.coef_top = torch.zeros(NPl, **f)        # div: Wasserstein seed of the penalised samples
+        self.HB4 = torch.zeros(NPl, 512, 4, 4, **f)  # div: primal adjoint entering the top stage
         self.pen = torch.zeros(1, **f)
         self.closs = torch.zeros(4, **f)                 # W, mean real, mean fake, penalty
         self.gloss = torch.zeros(1, **f)
         self.tbuf = torch.zeros(B, **f)
-        self.coef_gen = torch.full((B,), -1.0 / B, **f)
+        self.coef_gen = torch.full((B,), -1.0 / max(B, 1), **f)
         self.ones2B = torch.ones(2 * B, 1, **f)
-        self._init_coefs()
+        B = self.B
+        if not generator_only:
+            self._init_coefs()
 
         # ---- generator workspace ----
         g2c = (latent, 512, 256, 128, 64, 1)

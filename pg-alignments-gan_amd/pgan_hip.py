@@ -75,6 +75,9 @@ _SIGS = {
     "pgan_unpack_sites": [P, P, L, F, F, P],
     "pgan_pack_sites": [P, P, L, P],
     "pgan_gn_fwd_static": [P, P, P, P, P, I, I, I, P],
+    "pgan_fakebuf_step": [P, P, I, P, P, P, P, P, P, I, I, I, P, P, P],
+    "pgan_sample_genotypes": [P, P, L, I, P, I, P],
+    "pgan_parse_ms": [ctypes.c_char_p, L, I, I, I, P, P],
     "pgan_step_graph_begin": [P],
     "pgan_step_graph_end": [P, ctypes.POINTER(ctypes.c_void_p)],
     "pgan_step_graph_launch": [P, P],
@@ -110,6 +113,8 @@ for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option):
 
 import pgan_tape  # noqa: E402
 
+pgan_tape.error_type = PganError
+
 
 class _Enqueue:
     """An entry point that enqueues work on a stream: callable like the ctypes function; while a launch tape is being
@@ -122,14 +127,14 @@ class _Enqueue:
     def __call__(self, *args):
         t = pgan_tape.tape
         if t is not None:
-            t.append((self.fn, args))
+            t.append((self.fn, args, True))
         return self.fn(*args)
 
 
 class _Lib:
     """The loaded library with its enqueue entry points wrapped for tape recording (queries and host-side functions
     pass through untouched)."""
-    _HOST = ("pgan_parse_alignments", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
+    _HOST = ("pgan_parse_alignments", "pgan_parse_ms", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
              "pgan_step_graph_destroy")
 
     def __init__(self, lib):
@@ -239,9 +244,15 @@ class HipOps:
         self.ws_small = torch.empty(4096, dtype=torch.float32, device=self.device)
         self.d1_part = torch.zeros(max_samples * 16384, dtype=torch.float32, device=self.device)  # gaps stay 0
         self.max_samples = max_samples
-        self.ws_bn = torch.empty(_lib.pgan_bn_workspace_bytes(512), dtype=torch.uint8, device=self.device)
-        self.ws_gn = torch.empty(_lib.pgan_gn_workspace_bytes(4 * max_samples), dtype=torch.uint8, device=self.device)
-        self._ws_gn = {}
+        # Norm-kernel scratch (slice partial sums) is owned per stream: the engine runs chains of GroupNorm and
+        # BatchNorm launches concurrently on several streams, and a sums launch of one chain must not overwrite the
+        # partial sums another chain's apply launch is about to read.  Streams are registered up front
+        # (reserve_stream); a stream first seen while a capture is open is an error, not an allocation.
+        self._gn_bytes = int(_lib.pgan_gn_workspace_bytes(4 * max_samples))
+        self._bn_bytes = int(_lib.pgan_bn_workspace_bytes(512))
+        self._scratch = {}
+        self.capturing = False
+        self.reserve_stream(_stream())
         self._hold = False
         self._keep = []   # host-side arrays that must outlive an enqueue call
         # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
@@ -272,6 +283,8 @@ class HipOps:
         key = (w.data_ptr(), Cs, Cl)
         ent = self._planes.get(key)
         if ent is None:
+            if self.capturing:
+                raise PganError("weight planes were first requested inside a graph capture")
             nbytes = _lib.pgan_conv_x3_prep_bytes(Cs, Cl)
             ent = [torch.empty(nbytes, dtype=torch.uint8, device=self.device), False]
             self._planes[key] = ent
@@ -338,15 +351,31 @@ class HipOps:
         _check(_lib.pgan_rows_reduce_multi(pa, ld, oa, cc, n, r0, r1, r2, r3, _stream()), "pgan_rows_reduce_multi")
 
     # ---------------- GroupNorm family ----------------
+    def reserve_stream(self, handle: int) -> None:
+        """Allocate the norm-kernel scratch of a stream (raw handle) before work is enqueued on it."""
+        if handle not in self._scratch:
+            if self.capturing:
+                raise PganError("a stream without reserved scratch was used inside a graph capture")
+            self._scratch[handle] = (torch.empty(self._gn_bytes, dtype=torch.uint8, device=self.device),
+                                     torch.empty(self._bn_bytes, dtype=torch.uint8, device=self.device))
+
     def _gnws(self):
-        """Slice-sum scratch of the GroupNorm kernels, one per stream: chains of GroupNorm calls run concurrently on
-        different streams (the critic's two sample chains)."""
+        """Slice-sum scratch of the GroupNorm kernels for the current stream."""
         key = _stream()
-        ws = self._ws_gn.get(key)
-        if ws is None:
-            ws = self.ws_gn if not self._ws_gn else torch.empty_like(self.ws_gn)
-            self._ws_gn[key] = ws
-        return ws.data_ptr(), ws.numel()
+        ent = self._scratch.get(key)
+        if ent is None:
+            self.reserve_stream(key)
+            ent = self._scratch[key]
+        return ent[0].data_ptr(), self._gn_bytes
+
+    def _bnws(self):
+        """Slice-sum scratch of the BatchNorm kernels for the current stream."""
+        key = _stream()
+        ent = self._scratch.get(key)
+        if ent is None:
+            self.reserve_stream(key)
+            ent = self._scratch[key]
+        return ent[1].data_ptr(), self._bn_bytes
 
     def prepare_weights(self, weights) -> None:
         """Build the prepared copies of these convolution weights now, on the current stream, so that later uses on
@@ -396,7 +425,7 @@ class HipOps:
         B, C = a.shape[0] // groups, a.shape[1]
         assert B * groups == a.shape[0] and stats.numel() >= groups * 2 * C
         _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
-                                self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), momentum, int(groups), _stream()),
+                                *self._bnws(), B, C, _hw(a), momentum, int(groups), _stream()),
                "pgan_bn_fwd")
 
     def bn_fwd_partials(self, B, C, HW, groups=1) -> int:
@@ -438,7 +467,7 @@ class HipOps:
     def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
         B, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_bn_bwd(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
-                                _ptr(dbeta), self.ws_bn.data_ptr(), self.ws_bn.numel(), B, C, _hw(a), _stream()),
+                                _ptr(dbeta), *self._bnws(), B, C, _hw(a), _stream()),
                "pgan_bn_bwd")
 
     # ---------------- head ----------------
@@ -498,6 +527,25 @@ class HipOps:
         B = out_s.shape[0]
         _check(_lib.pgan_take_batch(_ptr(pool_s), _ptr(pool_p), _ptr(out_s), _ptr(out_p), cursor.data_ptr(),
                                     pool_s.shape[0], B, out_s[0].numel(), out_p[0].numel(), _stream()), "pgan_take_batch")
+
+    # ---------------- replay buffer / genotype sampling ----------------
+    def fakebuf_step(self, buf_s, buf_p, state, slots, new_s, new_p, out_s, out_p, rng, picks=None):
+        """FakeBuffer.add(new) then FakeBuffer.sample(B) on the device-resident ring (state: int32[4] head, count,
+        error flag, spare; slots: int32[B] scratch; picks: optional int32[B] logical indices instead of draws)."""
+        B, size = new_s.shape[0], buf_s.shape[0]
+        assert state.dtype == torch.int32 and state.numel() >= 4 and slots.dtype == torch.int32 and slots.numel() >= B
+        assert out_s.shape[0] == B and buf_p.shape[0] == size
+        if picks is not None:
+            assert picks.dtype == torch.int32 and picks.numel() >= B and picks.is_cuda
+        _check(_lib.pgan_fakebuf_step(_ptr(buf_s), _ptr(buf_p), size, state.data_ptr(), slots.data_ptr(), _ptr(new_s),
+                                      _ptr(new_p), _ptr(out_s), _ptr(out_p), B, new_s[0].numel(), new_p[0].numel(),
+                                      rng.data_ptr(), None if picks is None else picks.data_ptr(), _stream()),
+               "pgan_fakebuf_step")
+
+    def sample_genotypes(self, p, out, rng, require_variation=True):
+        assert p.dim() == 4 and p.shape[1] == 1 and p.shape[2] == 64 and tuple(out.shape) == tuple(p.shape)
+        _check(_lib.pgan_sample_genotypes(_ptr(p), _ptr(out), p.shape[0], p.shape[3], rng.data_ptr(),
+                                          int(require_variation), _stream()), "pgan_sample_genotypes")
 
     # ---------------- discriminator 1-D tower ----------------
     @staticmethod

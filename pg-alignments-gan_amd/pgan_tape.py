@@ -9,7 +9,8 @@ Engine / FusedTrainer) and the sequence of an iteration does not change.
 """
 from __future__ import annotations
 
-tape = None      # list of (callable, args) while recording, else None
+tape = None      # list of (callable, args, returns_status) while recording, else None
+error_type = RuntimeError      # pgan_hip sets this to PganError: what replay() raises for a failed library call
 
 
 def call(fn, *args, on_current_stream: bool = False):
@@ -22,9 +23,9 @@ def call(fn, *args, on_current_stream: bool = False):
         return fn(*args)
     if on_current_stream:
         import torch
-        t.append((_under, (torch.cuda.current_stream(), fn, args)))
+        t.append((_under, (torch.cuda.current_stream(), fn, args), False))
     else:
-        t.append((fn, args))
+        t.append((fn, args, False))
     tape = None                      # whatever fn enqueues itself is part of this one entry
     try:
         return fn(*args)
@@ -39,5 +40,9 @@ def _under(stream, fn, args):
 
 
 def replay(entries) -> None:
-    for fn, args in entries:
-        fn(*args)
+    """Library entry points return a status (0 = enqueued); anything else stops the replay with an error, as the same
+    call would have while recording."""
+    for fn, args, status in entries:
+        rc = fn(*args)
+        if status and rc:
+            raise error_type(f"{getattr(fn, '__name__', fn)} failed with code {rc} during tape replay")

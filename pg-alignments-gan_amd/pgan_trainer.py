@@ -41,7 +41,7 @@ class FusedTrainer:
         # its reduction is started right then, beside the rest of the backward; the remainder follows.
         self._early = []                      # (name, pending reduction)
         self.early_names = ("twod_conv_layers.9.weight",)
-        self.dist_active, self.sync_bn = False, False
+        self.dist_active, self.sync_bn, self._drain = False, False, False
         if world > 1 or process_group is not None:
             self.attach_process_group(process_group, sync_bn)
         # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks differ in the seed's high word
@@ -50,8 +50,13 @@ class FusedTrainer:
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
         self.pool_s: Optional[torch.Tensor] = None
         self.pool_p: Optional[torch.Tensor] = None
+        self.buf_s: Optional[torch.Tensor] = None    # replay buffer of generated alignments (enable_fake_buffer)
         self.graph = None
         self.tape = None
+        self.cap_stream = None       # capture(): the stream the step graph is recorded on
+        # generator-forwards-done mark of the batched iteration body (created here: nothing is created while a
+        # tape or a graph is being recorded)
+        self.gen_done = torch.cuda.Event() if self.dev.type == "cuda" else False
         self.use_graph = False       # step(): capture on the first call, replay afterwards
         self.use_tape = False        # step(): record a launch tape on the first call, replay it afterwards
         self.iterations = 0
@@ -68,6 +73,12 @@ class FusedTrainer:
         size) or over each rank's own samples (False: no collectives inside the generator)."""
         self.pg, self.dist_active = process_group, True
         self.tape = None
+        # A backend that stages device tensors through the host (gloo) runs each collective on streams of its own and
+        # completes it from a host thread: its copies then wait, from other hardware queues, on the engine's four busy
+        # compute streams, and a step was seen to stall on the GPU that way.  Such a backend gets an idle device at
+        # every collective (its result is host-synchronous anyway); RCCL enqueues on the calling stream and needs none.
+        import torch.distributed as dist
+        self._drain = self.dev.type == "cuda" and dist.is_initialized() and dist.get_backend(process_group) != "nccl"
         # collectives run on "the current stream": a launch tape replays them under the stream they were issued on
         self.eng.grad_ready = lambda name: pgan_tape.call(self._early_reduce, name, on_current_stream=True)
         self.sync_bn = True if sync_bn is None else bool(sync_bn)
@@ -121,48 +132,36 @@ class FusedTrainer:
         self.cursor.zero_()
 
     def enable_fake_buffer(self, size: int) -> None:
-        """Replay buffer of generated alignments (FakeBuffer, src/train_wgan_v2.py:98-117): every
-        critic step adds its fresh fakes to a bounded FIFO and trains on a batch drawn from it without
-        replacement.  Runs eagerly (sampling uses torch's device RNG)."""
+        """Replay buffer of generated alignments (FakeBuffer, src/train_wgan_v2.py:98-117): every critic step adds its
+        fresh fakes to a bounded FIFO resident in HBM and trains on a batch drawn from it without replacement.  Append,
+        draw (device Philox) and gather are kernels of the iteration like the others, so the buffered step runs on the
+        launch tape / step graph too.  buf_picks (int32[B] on the device, optional) replaces the random draws with given
+        logical indices (0 = oldest): a test drives it beside the reference's host deque."""
         B = self.eng.B
         assert size >= B
         self.buf_s = torch.zeros(size, 1, 64, 64, device=self.dev)
         self.buf_p = torch.zeros(size, 1, 64, device=self.dev)
-        self.buf_count, self.buf_head = 0, 0
-        self.tmp_s = torch.zeros(B, 1, 64, 64, device=self.dev)
-        self.tmp_p = torch.zeros(B, 1, 64, device=self.dev)
+        self.buf_state = torch.zeros(4, dtype=torch.int32, device=self.dev)     # head, count, error flag, spare
+        self.buf_slots = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        seed = int(self.rng_z[0]) + 2
+        self.rng_buf = torch.tensor([seed & 0x7FFFFFFF, self.rank, 0, 0], dtype=torch.int32, device=self.dev)
+        self.buf_picks = None
+        self.graph = self.tape = None
 
-    def _critic_buffered(self) -> None:
-        e, o = self.eng, self.ops
-        B, size = e.B, self.buf_s.shape[0]
-        o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
-        o.philox(e.Z, self.rng_z, True)
-        if e.loss == "gp":
-            o.philox(e.tbuf, self.rng_t, False)
-        e.gen_forward(e.Z, self.tmp_s, self.tmp_p)
-        pos = (self.buf_head + torch.arange(B, device=self.dev)) % size
-        self.buf_s[pos] = self.tmp_s
-        self.buf_p[pos] = self.tmp_p
-        self.buf_head = (self.buf_head + B) % size
-        self.buf_count = min(size, self.buf_count + B)
-        pick = torch.randperm(self.buf_count, device=self.dev)[:B]
-        e.X0[B:2 * B].copy_(self.buf_s[pick])
-        e.P0[B:2 * B].copy_(self.buf_p[pick])
-        e.critic_grads_resident(run_generator=False)
-        self._allreduce(e.D.gflat)
-        e.adam_d()
+    def _hand_fakes(self, src_s: torch.Tensor, src_p: torch.Tensor) -> None:
+        """This critic step's fake batch into the discriminator's input slots: the fresh fakes themselves, or (replay
+        buffer) the fresh fakes appended to the buffer and a batch drawn from it."""
+        e, o, B = self.eng, self.ops, self.eng.B
+        if self.buf_s is not None:
+            o.fakebuf_step(self.buf_s, self.buf_p, self.buf_state, self.buf_slots, src_s, src_p, e.X0[B:2 * B],
+                           e.P0[B:2 * B], self.rng_buf, self.buf_picks)
+        else:
+            o.affine(src_s, 1.0, 0.0, e.X0[B:2 * B])      # copies
+            o.affine(src_p, 1.0, 0.0, e.P0[B:2 * B])
 
     def step(self) -> None:
         """One iteration by the fastest available route."""
-        if getattr(self, "buf_s", None) is not None:
-            for _ in range(self.critic_iter):
-                self._critic_buffered()
-            self.ops.philox(self.eng.Z, self.rng_z, True)
-            self.eng.generator_grads_resident()
-            self._allreduce(self.eng.G.gflat)
-            self.eng.adam_g()
-            self.iterations += 1
-        elif self.tape is not None:
+        if self.tape is not None:
             self.replay_tape()
         elif self.use_tape:
             self.record_tape()
@@ -179,11 +178,15 @@ class FusedTrainer:
 
     def _bn_allreduce(self, part: torch.Tensor) -> None:
         import torch.distributed as dist
+        if self._drain:
+            torch.cuda.synchronize()
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _early_reduce(self, name: str) -> None:
         if name in self.early_names:
             import torch.distributed as dist
+            if self._drain:
+                torch.cuda.synchronize()
             work = dist.all_reduce(self.eng.D.g[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._early.append((name, work))
 
@@ -193,6 +196,8 @@ class FusedTrainer:
         if not self.dist_active:
             return
         import torch.distributed as dist
+        if self._drain:
+            torch.cuda.synchronize()
         store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else None
         if store is not None and self._early:
             done = sorted((store.offsets[n], store.offsets[n] + store.p[n].numel()) for n, _ in self._early)
@@ -226,8 +231,6 @@ class FusedTrainer:
         e, o = self.eng, self.ops
         B, gs, n = e.B, e.gside, self.critic_iter
         m = n + 1
-        if getattr(self, "gen_done", None) is None:
-            self.gen_done = torch.cuda.Event() if self.dev.type == "cuda" else False
         gs.fork()
         with gs:
             o.philox(e.Zw[:B], self.rng_z, True)
@@ -240,8 +243,7 @@ class FusedTrainer:
                 gs.join()
             elif i == 1 and self.gen_done:
                 pgan_tape.call(torch.cuda.current_stream().wait_event, self.gen_done)
-            o.affine(e.fake_s[i * B:(i + 1) * B], 1.0, 0.0, e.X0[B:2 * B])      # copies
-            o.affine(e.fake_p[i * B:(i + 1) * B], 1.0, 0.0, e.P0[B:2 * B])
+            self._hand_fakes(e.fake_s[i * B:(i + 1) * B], e.fake_p[i * B:(i + 1) * B])
             if i == 0:
                 gs.fork()
                 with gs:
@@ -284,8 +286,7 @@ class FusedTrainer:
                 o.philox(e.tbuf, self.rng_t, False)
             if self.fa_done[i] is not None:       # this step's fakes are complete
                 pgan_tape.call(torch.cuda.current_stream().wait_event, self.fa_done[i])
-            o.affine(self.fa_s[i], 1.0, 0.0, e.X0[B:2 * B])          # copies
-            o.affine(self.fa_p[i], 1.0, 0.0, e.P0[B:2 * B])
+            self._hand_fakes(self.fa_s[i], self.fa_p[i])
             e.critic_grads_resident(run_generator=False)
             self._reduce(e.D.gflat)
             e.adam_d()
@@ -313,8 +314,7 @@ class FusedTrainer:
             if e.loss == "gp":
                 o.philox(e.tbuf, self.rng_t, False)
             gs.join()                                   # this step's fakes are complete
-            o.affine(self.fk_s[i & 1], 1.0, 0.0, e.X0[B:2 * B])      # copies
-            o.affine(self.fk_p[i & 1], 1.0, 0.0, e.P0[B:2 * B])
+            self._hand_fakes(self.fk_s[i & 1], self.fk_p[i & 1])
             gs.fork()
             with gs:                                    # next forward, beside this critic step
                 o.philox(e.Z, self.rng_z, True)
@@ -336,28 +336,43 @@ class FusedTrainer:
         self.iterations += 1
 
     def capture(self) -> None:
-        """Run ONE iteration eagerly (it counts as a training iteration and warms every kernel on the
-        capture stream), then record the same launches into a hipGraph for replay()."""
+        """Run ONE iteration eagerly (it counts as a training iteration), then record the same launches into a hipGraph
+        for replay().  The eager pass runs on the stream that is captured afterwards, with the same side streams, so every
+        lazily created object of an iteration (per-stream scratch, prepared weight planes, events, variant buffers)
+        exists before the capture opens; inside it nothing may allocate (checked: the op backend refuses, and the
+        allocator's request count must not move).  The capture goes through the library's own entry points
+        (pgan_step_graph_begin / _end), not through torch's graph machinery."""
         if self.dist_active:
             raise RuntimeError("graph capture is used on the single-GPU path only")
+        from pgan_hip import StepGraph
+        if self.cap_stream is None:
+            self.cap_stream = torch.cuda.Stream(device=self.dev)
+            self.ops.reserve_stream(self.cap_stream.cuda_stream)
+        cap, cur = self.cap_stream, torch.cuda.current_stream()
         torch.cuda.synchronize()
-        if hasattr(self.ops, "invalidate_weight_planes"):
-            self.ops.invalidate_weight_planes()
-        side = torch.cuda.Stream(device=self.dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):     # one eager pass on the capture stream warms every kernel
+        self.ops.invalidate_weight_planes()
+        cap.wait_stream(cur)
+        with torch.cuda.stream(cap):
             self._iteration_body()
-        torch.cuda.current_stream().wait_stream(side)
+        cur.wait_stream(cap)
         torch.cuda.synchronize()
         self.iterations += 1
         tracked, dstep, gstep = self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step
-        if hasattr(self.ops, "invalidate_weight_planes"):
-            self.ops.invalidate_weight_planes()      # so that the recorded iteration starts by preparing them
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._iteration_body()
-        # capture records launches without running them: undo the host-side counters it bumped
-        self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step = tracked, dstep, gstep
+        self.ops.invalidate_weight_planes()      # so that the recorded iteration starts by preparing them
+        requests = torch.cuda.memory_stats(self.dev).get("allocation.all.allocated", 0)
+        graph = StepGraph()
+        self.ops.capturing = True
+        try:
+            with torch.cuda.stream(cap):
+                with graph:
+                    self._iteration_body()
+        finally:
+            self.ops.capturing = False
+            # capture records launches without running them: undo the host-side counters it bumped
+            self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step = tracked, dstep, gstep
+        if torch.cuda.memory_stats(self.dev).get("allocation.all.allocated", 0) != requests:
+            raise RuntimeError("device memory was requested while the step graph was being captured")
+        self.graph = graph
 
     def record_tape(self) -> None:
         """Run ONE iteration eagerly (it counts) while noting every enqueue call with its resolved arguments;
@@ -365,9 +380,12 @@ class FusedTrainer:
         third of its host time.  The op backend must be the HIP library (its entry points feed the tape)."""
         if not getattr(self.ops, "feeds_tape", False):
             raise RuntimeError("launch tapes need the HIP op backend")
-        if getattr(self, "buf_s", None) is not None:
-            raise RuntimeError("the replay-buffer path draws host-side random indices: no tape")
         torch.cuda.synchronize()
+        # the recorded iteration must start by preparing the weight planes: planes left fresh by an earlier forward
+        # (an evaluation pass, say) would put no preparation call on the tape, and every replay would convolve with
+        # the planes of old weights while Adam keeps stepping the fp32 ones
+        if hasattr(self.ops, "invalidate_weight_planes"):
+            self.ops.invalidate_weight_planes()
         pgan_tape.tape = entries = []
         try:
             self._iteration_body()
@@ -384,7 +402,7 @@ class FusedTrainer:
         self.eng.G.step += 1
 
     def replay(self) -> None:
-        self.graph.replay()
+        self.graph.launch()
         self.iterations += 1
         self.eng.g_batches_tracked += self.critic_iter + 1
         self.eng.D.step += self.critic_iter

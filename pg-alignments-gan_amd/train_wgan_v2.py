@@ -13,7 +13,7 @@ Differences from the reference, all deliberate:
     --shuffle_inds (row shuffle of each real alignment), --label_smooth/--label_noise;
   * an "epoch" is floor(num_in / batch / critic_iter) full iterations (the reference's extra
     generator step on the exhausted loader, :531-532,:639-640, is not reproduced);
-  * --plot (matplotlib/scikit-allel evaluation figures) is not part of this package.
+  * of the --plot outputs (matplotlib / scikit-allel figures) only the 2DSWD number (w_dist_pca.txt) is produced.
 """
 from __future__ import annotations
 
@@ -132,17 +132,34 @@ class DataGenerator(object):
 
 
 def read_ms_data(ms_lines):
-    """Parse ms text output (src/train_wgan_v2.py:311-330): every replicate starts with '//', then
-    'segsites:', 'positions: ...' and one 0/1 string per individual.  As in the reference the last
-    replicate is dropped (callers ask ms for batch_size + 1).  Returns (R,1,64,S), (R,S,1)."""
-    starts = [i for i, ln in enumerate(ms_lines) if "//" in ln]
+    """Parse ms text output, statement for statement as src/train_wgan_v2.py:311-330: a replicate starts at every
+    line containing '//'; its third line is 'positions: ...', split at single spaces with the first and the last
+    token dropped (ms ends the line with a space); the lines after it, except the last one before the next '//', are
+    one 0/1 string per individual; the last replicate is dropped (callers ask ms for batch_size + 1).
+    Returns (R,1,64,S), (R,S,1)."""
+    starts = [i for i, ln in enumerate(ms_lines) if "//" in ln] + [len(ms_lines)]
+    chunks = [ms_lines[starts[k]:starts[k + 1]] for k in range(len(starts) - 1)]
     X, P = [], []
-    for a, b in zip(starts[:-1], starts[1:]):
-        chunk = ms_lines[a:b]
-        P.append(np.array([u for u in chunk[2].split(" ")[1:] if u.strip() != ""], dtype=np.float32))
-        rows = [ln.strip() for ln in chunk[3:] if ln.strip() != ""]
-        X.append(np.array([[int(c) for c in r] for r in rows], dtype=np.float32))
+    for chunk in chunks[:-1]:
+        P.append(np.array([u for u in chunk[2].split(" ")[1:-1] if u != ""], dtype=np.float32))
+        X.append(np.array([[int(c) for c in r.replace("\n", "")] for r in chunk[3:-1]], dtype=np.float32))
     return np.expand_dims(np.array(X), 1), np.expand_dims(np.array(P), 2)
+
+
+def read_ms_text(text, rows=64, cols=64):
+    """read_ms_data on the whole text of an ms run through the native parser (pgan_parse_ms): same arrays
+    (R,1,rows,cols), (R,cols,1); ValueError for text that is not `rows` individuals x `cols` sites per replicate."""
+    import ctypes
+    from pgan_hip import _lib
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    reps = max(0, raw.count(b"//") - 1)
+    sites = np.empty((reps, 1, rows, cols), np.float32)
+    pos = np.empty((reps, cols, 1), np.float32)
+    got = _lib.pgan_parse_ms(raw, len(raw), rows, cols, reps, sites.ctypes.data_as(ctypes.c_void_p),
+                             pos.ctypes.data_as(ctypes.c_void_p))
+    if got < 0:
+        raise ValueError(f"ms output is not {rows} individuals x {cols} sites per replicate (parser code {got})")
+    return sites[:got], pos[:got]
 
 
 class SimulatorGenerator(object):
@@ -158,8 +175,7 @@ class SimulatorGenerator(object):
         self.cmd = [MS_PATH] + args
 
     def get_batch(self, label_smooth=True):
-        lines = subprocess.run(self.cmd, capture_output=True, text=True, check=True).stdout.split("\n")
-        sites, pos = read_ms_data(lines)
+        sites, pos = read_ms_text(subprocess.run(self.cmd, capture_output=True, check=True).stdout)
         if label_smooth:   # formula as written in the reference (line 349)
             ey = np.random.uniform(0.0, 0.1, sites.shape)
             sites = sites * (1 - ey) + 0.5 * sites
@@ -203,10 +219,27 @@ def switch_monomorphic(sites, positions, lower_bound, upper_bound):
     return sites, positions
 
 
+_GENOTYPE_RNG = {}
+
+
 def sample_genotypes_bernoulli(sites_tensor, require_variation=True):
     """src/train_wgan_v2.py:162-192: Bernoulli genotypes from the generator's probabilities; a column
     that came out monomorphic is redrawn and one individual, picked in proportion to its probability
-    of carrying the missing allele, is set to it."""
+    of carrying the missing allele, is set to it.  Tensors on the GPU are sampled there by one kernel
+    (pgan_sample_genotypes, device Philox seeded from Python's `random`); host tensors by the loop below."""
+    if sites_tensor.is_cuda:
+        from pgan_hip import HipOps
+        dev = sites_tensor.device
+        ent = _GENOTYPE_RNG.get(dev)
+        if ent is None:
+            ent = _GENOTYPE_RNG[dev] = (HipOps(dev, ws_floats=4, max_samples=1),
+                                        torch.tensor([random.randrange(1 << 31), random.randrange(1 << 31), 0, 0],
+                                                     dtype=torch.int32, device=dev))
+        p = sites_tensor.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(p)
+        with torch.cuda.device(dev):
+            ent[0].sample_genotypes(p, out, ent[1], require_variation)
+        return out
     out = torch.bernoulli(sites_tensor)
     if not require_variation:
         return out
@@ -289,20 +322,17 @@ def save_models(trainer, gen_path, disc_path):
     torch.save(d, disc_path)
 
 
-def evaluate_2dswd(trainer, real_sites, normalize, n=500, seed=None):
-    """2DSWD of n generated against n input alignments (src/train_wgan_v2.py:686-693,723): one generator
-    forward over all n (BatchNorm in training mode, running statistics updated, as in the reference),
-    undo --normalize, genotype with sample_genotypes_bernoulli, SFS -> PCA(2) -> sliced Wasserstein.
-    Of the reference's --plot outputs only this number (w_dist_pca.txt) is produced."""
-    import numpy as np
-    from data_processing_v2 import plot_sfs_pca
+def plotting_forward(trainer, normalize, n=1000):
+    """The generator pass the reference makes before every checkpoint, whether or not --plot is set
+    (src/train_wgan_v2.py:686-693): n = 1000 latent draws through the generator in training mode -- its BatchNorm
+    running statistics and batch counter step once more, and that is what the checkpoint then holds -- followed by
+    undoing --normalize and genotyping.  Returns the genotyped sites (n,1,64,64) on the device."""
     from pgan_engine import Engine
     eng = trainer.eng
-    n = min(n, real_sites.shape[0])
     ev = getattr(trainer, "_eval_engine", None)
     if ev is None or ev.B != n:
         ev = Engine(trainer.ops, n, trainer.dev, loss=eng.loss, act=eng.act, latent=eng.latent,
-                    g_store=eng.G, g_buffers=eng.Gbuf, d_store=eng.D)
+                    g_store=eng.G, g_buffers=eng.Gbuf, d_store=eng.D, generator_only=True)
         trainer._eval_engine = ev
     z = torch.randn(n, eng.latent, device=trainer.dev)
     fs = torch.empty(n, 1, 64, 64, device=trainer.dev)
@@ -311,7 +341,18 @@ def evaluate_2dswd(trainer, real_sites, normalize, n=500, seed=None):
     eng.g_batches_tracked += 1
     if normalize:
         fs = fs / 2 + 0.5
-    geno = sample_genotypes_bernoulli(fs.clamp(0, 1)).cpu().numpy()
+    return sample_genotypes_bernoulli(fs.clamp(0, 1))
+
+
+def evaluate_2dswd(trainer, real_sites, normalize, n=500, seed=None, generated=None):
+    """2DSWD of n generated against n input alignments (src/train_wgan_v2.py:723): SFS -> PCA(2) -> sliced
+    Wasserstein of the first n genotyped alignments of the plotting forward (`generated`; made here when not given).
+    Of the reference's --plot outputs only this number (w_dist_pca.txt) is produced."""
+    from data_processing_v2 import plot_sfs_pca
+    n = min(n, real_sites.shape[0])
+    if generated is None:
+        generated = plotting_forward(trainer, normalize, n)
+    geno = generated[:n].cpu().numpy()
     pick = np.random.choice(range(real_sites.shape[0]), n, replace=False)
     real = real_sites[pick]
     real = real.cpu().numpy() if hasattr(real, "cpu") else np.asarray(real)
@@ -331,7 +372,7 @@ def main(argv=None):
     act = "sigmoid" if args.gen == "sigGen" else "tanh"
     normalize = args.normalize or args.gen == "tanNorm"
     if args.plot:
-        logging.warning("--plot: the evaluation figures are not part of this package; continuing without them")
+        logging.warning("--plot: of the evaluation outputs only the 2DSWD number (w_dist_pca.txt) is produced")
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     # several GPUs (python -m torch.distributed.run --nproc-per-node N train_wgan_v2.py ...): --batch_size stays
@@ -395,8 +436,7 @@ def main(argv=None):
         trainer.set_pool(sites[rank::world], pos[rank::world], normalize=normalize)
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
-    else:
-        trainer.use_tape = True      # first iteration recorded as a launch tape, the rest replayed (one or several GPUs)
+    trainer.use_tape = True      # first iteration recorded as a launch tape, the rest replayed (one or several GPUs)
 
     iters_per_epoch = max(1, (num_in // (batch * world)) // critic_iter)
     for epoch in range(1, epochs + 1):
@@ -408,10 +448,11 @@ def main(argv=None):
                 logging.info("Epoch:\t%d/%d Discriminator loss: %6.8f Generator loss: %6.8f d_real: %6.8f d_fake: %6.8f"
                              % (epoch, epochs, w, g_loss, d_real, d_fake))
         if rank == 0 and save_freq != 0 and (epoch == 1 or epoch % save_freq == 0 or epoch == epochs):
+            generated = plotting_forward(trainer, normalize)      # before the save, as in the reference (:686-698)
             save_models(trainer, os.path.join(args.odir, "generator_model_{0:04d}.pt".format(epoch)),
                         os.path.join(args.odir, "discriminator_model_{0:04d}.pt".format(epoch)))
             if args.plot:
-                w = evaluate_2dswd(trainer, sites, normalize)
+                w = evaluate_2dswd(trainer, sites, normalize, generated=generated)
                 logging.info("Epoch:\t%d 2DSWD: %6.8f" % (epoch, w))
                 with open(os.path.join(args.odir, "w_dist_pca.txt"), "a") as f:   # src/train_wgan_v2.py:724-726
                     f.write(str(epoch) + "\t" + str(w) + "\n")

@@ -33,7 +33,8 @@ def test_train_cli(tmp_path, extra):
     assert {k: tuple(v.shape) for k, v in g.items()} == want_g
     assert {k: tuple(v.shape) for k, v in d.items()} == orc.disc_param_shapes()
     iters = 2 * ((96 // 8) // 5)
-    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters
+    # every save is preceded by the 1000-sample plotting forward (src/train_wgan_v2.py:686-698): two saves so far
+    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 2
     assert all(bool(torch.isfinite(v.float()).all()) for v in list(g.values()) + list(d.values()))
     import layers
     G = layers.DC_Generator_Leaky_Sig(64, 128, 0.1, 1, 4)
@@ -42,7 +43,7 @@ def test_train_cli(tmp_path, extra):
 
 def test_train_cli_writes_2dswd(tmp_path):
     """--plot: the 2DSWD evaluation runs at every saved epoch and is appended to w_dist_pca.txt
-    (src/train_wgan_v2.py:723-726); its generator forward counts as a BatchNorm batch, as in the reference."""
+    (src/train_wgan_v2.py:723-726) from the genotypes of the plotting forward made before the save."""
     import train_wgan_v2 as tw
     idir, odir = tmp_path / "sims", tmp_path / "out"
     idir.mkdir()
@@ -55,7 +56,7 @@ def test_train_cli_writes_2dswd(tmp_path):
     assert all(np.isfinite(v) and v > 0 for v in vals)
     g = torch.load(odir / "generator_model_0002.pt", weights_only=True)
     iters = 2 * ((96 // 8) // 5)
-    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 1     # saved before epoch 2's evaluation
+    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 6 * iters + 2     # the two saves' plotting forwards
 
 
 

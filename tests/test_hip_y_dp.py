@@ -57,14 +57,6 @@ def _worker(rank, world, port, loss, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    # gloo stages CUDA tensors through high-priority streams; a high-priority stream waiting for work of the
-    # default-priority compute streams can stall the GPU here, so every collective starts on an idle device
-    reduce_ = dist.all_reduce
-
-    def all_reduce_idle(*a, **k):
-        torch.cuda.synchronize()
-        return reduce_(*a, **k)
-    dist.all_reduce = all_reduce_idle
     tr = FusedTrainer(HipOps(dev), B // world, dev, loss=loss, process_group=dist.group.WORLD, rank=rank, world=world)
     assert tr.sync_bn
     _load(tr)

@@ -96,6 +96,19 @@ def test_ms_parser_and_buffers():
     assert X.shape == (2, 1, 64, 5) and P.shape == (2, 5, 1)     # last replicate dropped, as in the reference
     assert np.array_equal(X[1, 0], reps[1][1].astype(np.float32))
     assert np.allclose(P[0, :, 0], np.round(reps[0][0], 4), atol=1e-4)
+    # the native parser (pgan_parse_ms) returns the same arrays, bit for bit
+    Xn, Pn = tw.read_ms_text("\n".join(lines), rows=64, cols=5)
+    assert Xn.shape == X.shape and Pn.shape == P.shape and np.array_equal(Xn, X) and np.array_equal(Pn, P)
+    # a positions line without the trailing space loses its last value in the reference: 4 of 5 -> rejected
+    broken = [ln.rstrip(" ") if ln.startswith("positions") else ln for ln in lines]
+    assert tw.read_ms_data(broken)[1].shape == (2, 4, 1)
+    with pytest.raises(ValueError):
+        tw.read_ms_text("\n".join(broken), rows=64, cols=5)
+    with pytest.raises(ValueError):
+        tw.read_ms_text("\n".join(lines).replace("segsites: 5\n", "segsites: 5\nextra\n", 1), rows=64, cols=5)
+    with pytest.raises(ValueError):
+        tw.read_ms_text("\n".join(lines[:10] + ["0x010"] + lines[11:]), rows=64, cols=5)
+    assert tw.read_ms_text("no replicates here\n")[0].shape[0] == 0
     buf = tw.FakeBuffer(max_size=8)
     buf.add(torch.arange(6).float().view(6, 1), torch.arange(6).float().view(6, 1))
     buf.add(torch.arange(6, 12).float().view(6, 1), torch.arange(6, 12).float().view(6, 1))
