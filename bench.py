@@ -3,22 +3,24 @@
 
 One "step" = one full iteration of the reference trainer's inner loop
 (/root/reference/src/train_wgan_v2.py:516-634): critic_iter (5) critic updates + 1 generator
-update at batch 64 per GPU, gp loss, sigmoid generator (BASELINE.json configs[1]).  Inputs are
-synthetic ms-style 64x64 alignments resident in HBM before the timed region; z and t are drawn on
-the device.  Metric: train alignments/sec = critic_iter * global_batch * steps / wall time.
+update.  --config picks the BASELINE.json configuration (default 1 = configs[1]: sigmoid generator, gp loss,
+batch 64 per GPU; 2 = configs[2]: tanh generator + --normalize, global batch 512 over the GPUs; 3 = configs[3]: div
+loss + replay buffer of 20 batches + row-permuted input, global batch 256).  Inputs are synthetic ms-style 64x64
+alignments resident in HBM before the timed region; z and t are drawn on the device.
+Metric: train alignments/sec = critic_iter * global_batch * steps / wall time.
 
   python bench.py --gpus 1 --steps 50 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (implicit-GEMM convolutions;
-DOWN and UP run on the bf16 matrix pipe as six exact partial products per fp32 product, WGRAD on the fp32
-matrix pipe): `achieved` counts the MFMA flops the family executes on its pipe (six times the algorithmic
-fp32 flops on the bf16 pipe) against that pipe's dense peak; `algorithmic_tflops` is the fp32-equivalent
-rate.  After the timed region one iteration's launches are noted and every launch shape is
-timed with HIP events on the launch stream around back-to-back launches (eager per-launch events
-would time host launch gaps, and launches inside a replayed graph cannot carry events);
-`cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step) on this box's
-host cores over a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (implicit-GEMM convolutions; all three
+kinds run on the bf16 matrix pipe as six exact partial products per fp32 product): `achieved` counts the MFMA flops
+the family executes on its pipe (six times the algorithmic fp32 flops) against that pipe's dense peak;
+`algorithmic_tflops` is the fp32-equivalent rate.  After the timed region one iteration's launches are noted and
+every launch shape is timed with HIP events on the launch stream around back-to-back launches (eager per-launch
+events would time host launch gaps, and launches inside a replayed graph cannot carry events).  `hbm_kernels` does
+the same for the bandwidth-bound kernels (norms, single-channel convolutions, Adam) against their algorithmic bytes.
+`cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step, with the reference's wasted
+backward passes included) on this box's host cores over a bounded sample.
 """
 from __future__ import annotations
 
@@ -59,12 +61,53 @@ def synthetic_pool(n, seed):
     return torch.from_numpy(sites[:, None]), torch.from_numpy(pos[:, None])
 
 
+def _numel(t):
+    n = 1
+    for d in t.shape:
+        n *= d
+    return n
+
+
 class RecordingOps:
-    """Proxy around HipOps that, while `recording`, notes every conv-family launch (kernel, shape,
-    the actual argument tensors) of an iteration so that each launch shape can be timed afterwards."""
-    NAMES = ("conv_down", "conv_up", "conv_wgrad")
+    """Proxy around HipOps that, while `recording`, notes every launch of the kernels listed in DESCRIBE (kernel,
+    shape, the actual argument tensors) of an iteration so that each launch shape can be timed afterwards."""
 
     _OWN = ("_ops", "recording", "calls")
+
+    # name -> (key, algorithmic flops, algorithmic bytes) of one call
+    @staticmethod
+    def _conv(kind):
+        def d(a, k):
+            if kind == "conv_down":
+                x, w = a[0], a[1]
+                n, cs, cl, hs = x.shape[0], w.shape[0], w.shape[1], x.shape[2] // 2
+            elif kind == "conv_up":
+                y, w = a[0], a[1]
+                n, cs, cl, hs = y.shape[0], w.shape[0], w.shape[1], y.shape[2]
+            else:
+                ya, x = a[0], a[1]
+                n, cs, cl, hs = ya.shape[0], ya.shape[1], x.shape[1], ya.shape[2]
+            small, large, wts = n * cs * hs * hs, n * cl * 4 * hs * hs, cs * cl * 16
+            return (kind, n, cs, cl, hs), 2.0 * n * cs * cl * 16 * hs * hs, 4.0 * (small + large + wts)
+        return d
+
+    @staticmethod
+    def _stream_op(kind, tensors):
+        """tensors: how many activation-sized tensors the op reads + writes"""
+        def d(a, k):
+            t = a[0] if a[0] is not None else a[1]
+            n = tensors - (1 if (kind == "gn_bwd2" and a[0] is None) else 0)
+            return (kind,) + tuple(t.shape), 0.0, 4.0 * n * _numel(t)
+        return d
+
+    DESCRIBE = {
+        "conv_down": _conv.__func__("conv_down"), "conv_up": _conv.__func__("conv_up"),
+        "conv_wgrad": _conv.__func__("conv_wgrad"),
+        "gn_fwd": _stream_op.__func__("gn_fwd", 2), "gn_bwd": _stream_op.__func__("gn_bwd", 4),
+        "gn_jvp": _stream_op.__func__("gn_jvp", 4), "gn_bwd2": _stream_op.__func__("gn_bwd2", 6),
+        "bn_fwd": _stream_op.__func__("bn_fwd", 2), "bn_bwd": _stream_op.__func__("bn_bwd", 4),
+        "adam": lambda a, k: (("adam", _numel(a[0])), 0.0, 28.0 * _numel(a[0])),
+    }
 
     def __init__(self, ops):
         self._ops = ops
@@ -79,21 +122,13 @@ class RecordingOps:
 
     def __getattr__(self, name):
         fn = getattr(self._ops, name)
-        if name not in self.NAMES or not callable(fn):
+        if name not in self.DESCRIBE or not callable(fn):
             return fn
 
         def wrapped(*a, **k):
             if self.recording:
-                if name == "conv_down":
-                    x, w = a[0], a[1]
-                    n, cs, cl, hs = x.shape[0], w.shape[0], w.shape[1], x.shape[2] // 2
-                elif name == "conv_up":
-                    y, w = a[0], a[1]
-                    n, cs, cl, hs = y.shape[0], w.shape[0], w.shape[1], y.shape[2]
-                else:
-                    ya, x = a[0], a[1]
-                    n, cs, cl, hs = ya.shape[0], ya.shape[1], x.shape[1], ya.shape[2]
-                rec = self.calls.setdefault((name, n, cs, cl, hs), dict(count=0, args=(a, k)))
+                key, flops, nbytes = self.DESCRIBE[name](a, k)
+                rec = self.calls.setdefault(key, dict(count=0, args=(a, k), flops=flops, bytes=nbytes))
                 rec["count"] += 1
             return fn(*a, **k)
         return wrapped
@@ -114,35 +149,78 @@ class RecordingOps:
             e.record()
             e.synchronize()
             ms = s.elapsed_time(e) / reps
-            n, cs, cl, hs = key[1:]
-            out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=2.0 * n * cs * cl * 16 * hs * hs)
+            out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=rec["flops"], bytes=rec["bytes"])
         return out
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(loss, act, batch, critic_iter, iters=3):
+    """The reference's step on the host cores: the CPU oracle with the reference's wasted work included (gp: fakes
+    left attached, so every critic backward also runs through the generator; the generator step's backward also
+    computes the discriminator's weight gradients), on all cores of this process and on one thread (the reference's
+    SLURM script asks for one core, /root/reference/slurm/train_gan_conda.sh:8), plus the same without the wasted
+    work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dcwgan_oracle as orc
     torch.manual_seed(0)
-    gp_ = orc.make_params(orc.gen_param_shapes(), 20261)
-    dp = orc.make_params(orc.disc_param_shapes(), 20262)
-    gbuf = orc.make_gen_buffers()
-    d_opt, g_opt = orc.AdamState(dp), orc.AdamState(gp_)
     rs, rp = orc.synthetic_alignments(batch * critic_iter, 20263)
+    if act == "tanh":
+        rs, rp = (rs - 0.5) / 0.5, (rp - 0.5) / 0.5
     batches = [(rs[i * batch:(i + 1) * batch], rp[i * batch:(i + 1) * batch]) for i in range(critic_iter)]
 
-    def one():
-        zs = [torch.randn(batch, 128, 1, 1) for _ in range(critic_iter + 1)]
-        ts = [torch.rand(batch, 1, 1, 1) for _ in range(critic_iter)]
-        orc.train_iteration(dp, gp_, gbuf, d_opt, g_opt, batches, zs, ts if loss == "gp" else None, loss, 10.0, act)
+    def run(n, reference_cost):
+        gp_ = orc.make_params(orc.gen_param_shapes(), 20261)
+        dp = orc.make_params(orc.disc_param_shapes(), 20262)
+        gbuf = orc.make_gen_buffers()
+        d_opt, g_opt = orc.AdamState(dp), orc.AdamState(gp_)
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        one()
-    dt = time.perf_counter() - t0
-    return dict(value=critic_iter * batch * iters / dt, unit="alignments/sec", cores=torch.get_num_threads(),
-                kind="port", sample=f"{iters} full iterations (5 critic + 1 generator step, batch {batch}) after 1 "
-                                     f"warm-up, stock-PyTorch CPU oracle, {dt / iters:.2f} s/iteration")
+        def one():
+            zs = [torch.randn(batch, 128, 1, 1) for _ in range(critic_iter + 1)]
+            ts = [torch.rand(batch, 1, 1, 1) for _ in range(critic_iter)]
+            orc.train_iteration(dp, gp_, gbuf, d_opt, g_opt, batches, zs, ts if loss == "gp" else None, loss, 10.0, act,
+                                reference_cost=reference_cost)
+        if n > 1:
+            one()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one()
+        return (time.perf_counter() - t0) / n
+
+    cores = torch.get_num_threads()
+    per_it = run(iters, True)
+    lean = run(iters, False)
+    torch.set_num_threads(1)
+    try:
+        one_thread = run(1, True)
+    finally:
+        torch.set_num_threads(cores)
+    rate = lambda sec: round(critic_iter * batch / sec, 2)
+    return dict(value=rate(per_it), unit="alignments/sec", cores=cores, kind="port", cpu_model=_cpu_model(),
+                one_thread=dict(value=rate(one_thread), cores=1, sample=f"1 full iteration, {one_thread:.2f} s"),
+                without_wasted_backward=dict(value=rate(lean), cores=cores, sample=f"{iters} full iterations, {lean:.2f} s each"),
+                sample=f"{iters} full iterations (5 critic + 1 generator step, batch {batch}, {loss} loss, {act} generator) "
+                       f"after 1 warm-up, stock-PyTorch CPU oracle doing the reference's work (fakes attached in gp critic "
+                       f"steps, discriminator weight gradients in the generator step), {per_it:.2f} s/iteration")
+
+
+CONFIGS = {
+    # BASELINE.json configs[i] -> defaults (explicit flags override them)
+    1: dict(loss="gp", act="sigmoid", batch=64, global_batch=None, buffer=0, permute=False,
+            name="configs[1]: DCWGAN-GP sigGen 64x64, batch 64, fp32, single MI355X"),
+    2: dict(loss="gp", act="tanh", batch=64, global_batch=512, buffer=0, permute=False,
+            name="configs[2]: DCWGAN-GP tanNorm + --normalize, 64x64, global batch 512 data-parallel"),
+    3: dict(loss="div", act="sigmoid", batch=32, global_batch=256, buffer=20, permute=True,
+            name="configs[3]: DCWGAN-GP div loss + --use_buffer + --permute, 64x64, global batch 256"),
+}
 
 
 def main():
@@ -150,9 +228,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64, help="batch per GPU")
-    ap.add_argument("--loss", default="gp", choices=["gp", "div"])
-    ap.add_argument("--act", default="sigmoid", choices=["sigmoid", "tanh"])
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: 1 sigGen gp batch 64 (default), 2 tanNorm + normalize, "
+                         "3 div + replay buffer + permute")
+    ap.add_argument("--batch", type=int, default=None, help="batch per GPU (default: the configuration's)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="fixed total batch split over the GPUs (strong scaling); with --config 2 / 3 on several GPUs "
+                         "the configuration's global batch is the default")
+    ap.add_argument("--loss", default=None, choices=["gp", "div"])
+    ap.add_argument("--act", default=None, choices=["sigmoid", "tanh"])
+    ap.add_argument("--use-buffer", type=int, default=None, help="replay buffer of this many batches (0: none)")
+    ap.add_argument("--permute", action="store_true", default=None, help="row-permuted real alignments")
     ap.add_argument("--critic-iter", type=int, default=5)
     ap.add_argument("--route", default="auto", choices=["auto", "eager", "tape", "graph"],
                     help="how an iteration is enqueued (auto: the fastest of the available ones, measured)")
@@ -177,6 +263,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = CONFIGS[args.config]
+    args.loss = args.loss or cfg["loss"]
+    args.act = args.act or cfg["act"]
+    buffer_n = cfg["buffer"] if args.use_buffer is None else args.use_buffer
+    permute = cfg["permute"] if args.permute is None else args.permute
+    scaling = "weak"
+    gb = args.global_batch
+    if gb is None and args.batch is None and world > 1 and cfg["global_batch"]:
+        gb = cfg["global_batch"]           # the configuration is quoted on a fixed global batch
+    if gb is not None:
+        if gb % world:
+            raise SystemExit(f"--global-batch {gb} is not a multiple of the {world} GPUs")
+        args.batch, scaling = gb // world, "strong"
+    elif args.batch is None:
+        args.batch = cfg["batch"]
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     pg = None
@@ -201,9 +302,13 @@ def main():
                     v = (torch.rand(sh, generator=gen) * 2 - 1) / fan ** 0.5
                 store.p[k].copy_(v)
         t.set_pool(ps, pp, normalize=(args.act == "tanh"))
+        if permute:          # --permute: every alignment's individuals in a new random order at the start of an epoch
+            t.shuffle_pool(rows=True)
+        if buffer_n:
+            t.enable_fake_buffer(buffer_n * args.batch)
         return t
 
-    ops = HipOps(dev)
+    ops = HipOps(dev, max_samples=max(1024, 4 * args.batch))
     timed = RecordingOps(ops)
     tr = make_trainer(timed)
     if use_dist:
@@ -275,7 +380,7 @@ def main():
         dt = float(tmax)
     losses = tr.losses()
 
-    # per-kernel timing of the conv family: note one iteration's launches, then time each shape
+    # per-kernel timing: note one iteration's launches, then time each launch shape on its own
     timed.recording = True
     tr.iteration()
     timed.recording = False
@@ -283,8 +388,9 @@ def main():
     summ = timed.time_shapes(args.profile_iters)
 
     if rank == 0:
+        conv = {k: v for k, v in summ.items() if k[0].startswith("conv_")}
         fam = {}
-        for (name, n, cs, cl, hs), r in summ.items():
+        for (name, n, cs, cl, hs), r in conv.items():
             f = fam.setdefault(name, dict(total_ms=0.0, flops=0.0, calls=0))
             f["total_ms"] += r["total_ms"]
             f["flops"] += r["flops"] * r["calls"]
@@ -293,31 +399,45 @@ def main():
         x3 = getattr(ops, "precision", "fp32") == "x3"
         wg3 = x3 and getattr(ops, "wgrad_x3", False)
         pipe = {k: ("bf16" if (x3 and (k != "conv_wgrad" or wg3)) else "fp32") for k in fam}
+        cname = lambda k: f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]"
+        # bandwidth-bound kernels: algorithmic bytes (tensors read + written once; Adam 28 B per parameter) over the
+        # isolated launch duration, against the 8 TB/s HBM peak
+        hbm = {}
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+            single = k[0].startswith("conv_") and k[3] == 1
+            if k[0].startswith("conv_") and not single:
+                continue
+            label = cname(k) if single else f"{k[0]}{list(k[1:])}"
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            hbm[label] = dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2), algorithmic_MB=round(v["bytes"] / 1e6, 3),
+                              GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4))
         roofline = None
         if dom:
             f = fam[dom]
             alg = f["flops"] / (f["total_ms"] * 1e-3) / 1e12
             mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if pipe[dom] == "bf16" else (1.0, PEAK_FP32_MFMA_TFLOPS)
             ach = alg * mult
-            per_shape = {f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]":
-                         dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
-                              tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in sorted(summ.items())}
-            # HBM traffic of the family's largest launch shape from the committed PMC passes (bytes per launch)
-            traffic, traffic_of = None, None
+            per_shape = {cname(k): dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
+                                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
+                         for k, v in sorted(conv.items())}
+            # HBM traffic of the family's largest launch shape from the committed PMC passes (bytes per launch):
+            # rocprofv3 --pmc runs of tools/onekernel.py, separate passes for FETCH_SIZE and WRITE_SIZE; the file names
+            # the commit its kernels were built from
+            traffic, traffic_of, traffic_at = None, None, None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                name = lambda k: f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]"
-                have = [k for k in summ if k[0] == dom and name(k) in pm]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                traffic_at = pm.get("measured_at")
+                have = [k for k in conv if k[0] == dom and cname(k) in pm]
                 if have:       # the measured shape with the largest time share
-                    big = max(have, key=lambda k: summ[k]["total_ms"])
-                    traffic = (pm[name(big)]["FETCH_SIZE_KB"] + pm[name(big)]["WRITE_SIZE_KB"]) * 1024
-                    traffic_of = name(big)
+                    big = max(have, key=lambda k: conv[k]["total_ms"])
+                    traffic = (pm[cname(big)]["FETCH_SIZE_KB"] + pm[cname(big)]["WRITE_SIZE_KB"]) * 1024
+                    traffic_of = cname(big)
             except (OSError, ValueError):
                 pass
             kname = dom + "_x3_kernel" if pipe[dom] == "bf16" else dom + "_kernel"
             roofline = dict(bound="mfma", kernel=f"{kname} ({pipe[dom]} matrix pipe, implicit GEMM)",
                             achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                            traffic=traffic, traffic_shape=traffic_of,
+                            traffic=traffic, traffic_shape=traffic_of, traffic_measured_at=traffic_at,
                             algorithmic_tflops=round(alg, 3),
                             algorithmic_frac_of_fp32_mfma_peak=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                             note=("achieved / peak / frac price the bf16 MFMA work actually executed (6 partial products "
@@ -338,25 +458,27 @@ def main():
                             per_shape=per_shape)
         nalign = args.critic_iter * args.batch * world * args.steps
         value = nalign / dt
+        extras = (f", replay buffer of {buffer_n} batches" if buffer_n else "") + (", row-permuted input" if permute else "")
         out = dict(metric="train alignments/sec (WGAN-GP step, 64x64)", value=round(value, 2), unit="alignments/sec",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
                    arithmetic=("fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
                                "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe"
                                if x3 else "fp32 throughout (fp32 matrix pipe)"),
-                   config=dict(workload=f"configs[1]: DCWGAN-GP {args.act}Gen 64x64, batch {args.batch}/GPU, fp32, "
-                                        f"{args.loss} loss, {args.critic_iter} critic + 1 generator step per step",
-                               global_batch=args.batch * world, critic_iter=args.critic_iter, loss=args.loss,
-                               hip_graph=bool(use_graph), launch=route, parallelism=f"dp{world}",
+                   config=dict(workload=f"{cfg['name']} -- run as {args.act} generator"
+                                        f"{' + normalize' if args.act == 'tanh' else ''}, {args.loss} loss, batch {args.batch}/GPU"
+                                        f"{extras}, {args.critic_iter} critic + 1 generator step per step",
+                               baseline_config=args.config, global_batch=args.batch * world, critic_iter=args.critic_iter,
+                               loss=args.loss, hip_graph=bool(use_graph), launch=route, parallelism=f"dp{world}",
                                batchnorm=("global batch statistics (per-channel sums all-reduced)" if tr.sync_bn
                                           else "per-GPU batch statistics")),
                    step_tflops=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12, 3),
                    step_frac_of_fp32_mfma_peak=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
-                   roofline=roofline)
+                   roofline=roofline, hbm_kernels=hbm)
         if world == 1 and x3 and not args.no_fp32_pipe:
             # the same step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
-            t32 = make_trainer(HipOps(dev, precision="fp32"))
+            t32 = make_trainer(HipOps(dev, precision="fp32", max_samples=max(1024, 4 * args.batch)))
             n32 = max(5, args.steps // 2)
             if best == "graph":
                 t32.capture()

@@ -269,15 +269,22 @@ def _leafify(p: ParamDict) -> ParamDict:
 def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_s: Tensor, real_p: Tensor,
                  z: Tensor, loss: str = "gp", lam: float = 10.0, t: Optional[Tensor] = None,
                  act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None,
-                 masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None
-                 ) -> Tuple[Tensor, ParamDict]:
+                 masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None,
+                 reference_cost: bool = False) -> Tuple[Tensor, ParamDict]:
     """One critic loss + its gradient w.r.t. every discriminator parameter
     (src/train_wgan_v2.py:534-609).  The generator forward runs in training mode and updates
     `gbuf`; its output is treated as a constant (in gp mode the reference leaves it attached,
-    which only fills generator .grad fields that are zeroed before use, lines 538-539,619)."""
+    which only fills generator .grad fields that are zeroed before use, lines 538-539,619).
+    reference_cost: do that wasted work too (gp: the fakes stay attached and the backward also runs
+    through the generator) -- same results, the reference's running time; for CPU timing only."""
     B = real_s.size(0)
-    with torch.no_grad():
-        fake_s, fake_p = gen_forward(gp_, gbuf, z, act, acts, masks)
+    GP = None
+    if reference_cost and loss == "gp":
+        GP = _leafify(gp_)
+        fake_s, fake_p = gen_forward(GP, gbuf, z, act, acts, masks)
+    else:
+        with torch.no_grad():
+            fake_s, fake_p = gen_forward(gp_, gbuf, z, act, acts, masks)
     P = _leafify(dp)
     if loss == "div":
         real_s = real_s.detach().clone().requires_grad_(True)
@@ -294,7 +301,8 @@ def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_
         raise ValueError(loss)
     w = d_fake.mean() - d_real.mean() + pen
     names = list(P.keys())
-    grads = torch.autograd.grad(w, [P[n] for n in names], allow_unused=True)
+    extra = [] if GP is None else list(GP.values())
+    grads = torch.autograd.grad(w, [P[n] for n in names] + extra, allow_unused=True)[:len(names)]
     g = {n: (torch.zeros_like(P[n]) if gi is None else gi.detach()) for n, gi in zip(names, grads)}
     if aux is not None:
         aux.update(fake_sites=fake_s.detach(), fake_pos=fake_p.detach(), d_real=d_real.detach(),
@@ -304,14 +312,18 @@ def critic_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], real_
 
 def generator_grads(dp: ParamDict, gp_: ParamDict, gbuf: Optional[ParamDict], z: Tensor,
                     act: str = "sigmoid", aux: Optional[Dict[str, Tensor]] = None,
-                    masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None
-                    ) -> Tuple[Tensor, ParamDict]:
-    """src/train_wgan_v2.py:619-633: loss = -mean(D(G(z))), gradient w.r.t. generator params."""
+                    masks: Optional[Dict[str, Tensor]] = None, acts: Optional[Dict[str, Tensor]] = None,
+                    reference_cost: bool = False) -> Tuple[Tensor, ParamDict]:
+    """src/train_wgan_v2.py:619-633: loss = -mean(D(G(z))), gradient w.r.t. generator params.
+    reference_cost: the backward also computes the discriminator's parameter gradients, as the reference's
+    gen_loss.backward() does before the next disc zero_grad discards them (line 567); for CPU timing only."""
     P = _leafify(gp_)
     xs, xp = gen_forward(P, gbuf, z, act, acts, masks)
-    loss = -disc_forward(dp, xs, xp, acts, masks, "d_main").mean()
+    DP = _leafify(dp) if reference_cost else dp
+    loss = -disc_forward(DP, xs, xp, acts, masks, "d_main").mean()
     names = list(P.keys())
-    grads = torch.autograd.grad(loss, [P[n] for n in names])
+    extra = list(DP.values()) if reference_cost else []
+    grads = torch.autograd.grad(loss, [P[n] for n in names] + extra)[:len(names)]
     if aux is not None:
         aux.update(fake_sites=xs.detach(), fake_pos=xp.detach())
     return loss.detach(), {n: gi.detach() for n, gi in zip(names, grads)}
@@ -354,8 +366,8 @@ def kink_margin(acts: Dict[str, Tensor]) -> float:
 
 def train_iteration(dp: ParamDict, gp_: ParamDict, gbuf: ParamDict, d_opt: AdamState, g_opt: AdamState,
                     real_batches: List[Tuple[Tensor, Tensor]], zs: List[Tensor], ts: Optional[List[Tensor]],
-                    loss: str = "gp", lam: float = 10.0, act: str = "sigmoid", normalize: bool = False
-                    ) -> Tuple[float, float]:
+                    loss: str = "gp", lam: float = 10.0, act: str = "sigmoid", normalize: bool = False,
+                    reference_cost: bool = False) -> Tuple[float, float]:
     """One iteration of src/train_wgan_v2.py:516-634: len(real_batches) critic steps, then one
     generator step with zs[-1].  `normalize` applies (x-0.5)/0.5 to sites and positions
     (lines 453,519-521).  Updates dp/gp_/gbuf/optimiser state in place."""
@@ -363,8 +375,9 @@ def train_iteration(dp: ParamDict, gp_: ParamDict, gbuf: ParamDict, d_opt: AdamS
     for h, (rs, rp) in enumerate(real_batches):
         if normalize:
             rs, rp = (rs - 0.5) / 0.5, (rp - 0.5) / 0.5
-        w, g = critic_grads(dp, gp_, gbuf, rs, rp, zs[h], loss, lam, None if ts is None else ts[h], act)
+        w, g = critic_grads(dp, gp_, gbuf, rs, rp, zs[h], loss, lam, None if ts is None else ts[h], act,
+                            reference_cost=reference_cost)
         d_opt.apply(dp, g)
-    gl, g = generator_grads(dp, gp_, gbuf, zs[len(real_batches)], act)
+    gl, g = generator_grads(dp, gp_, gbuf, zs[len(real_batches)], act, reference_cost=reference_cost)
     g_opt.apply(gp_, g)
     return float(w), float(gl)
