@@ -234,6 +234,8 @@ class Engine:
         # called with a parameter name right after that discriminator weight gradient has been enqueued (on
         # the stream it was enqueued on): lets a data-parallel driver start reducing it during the backward
         self.grad_ready = None
+        # the same for the generator's 2-D convolution weight gradients (generator step's backward)
+        self.gen_grad_ready = None
 
         NT = self.NT
         self.generator_only = bool(generator_only)
@@ -500,6 +502,8 @@ class Engine:
             self.wside.fork()
             with self.wside:      # the weight gradient beside the input-gradient chain
                 o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
+                if self.gen_grad_ready is not None:
+                    self.gen_grad_ready(f"twod_conv_layers.{3 * i}.weight")
             o.conv_down(up, w, self.gdH[i])
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
             self._bn_bwd(n, self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],

@@ -39,8 +39,12 @@ class FusedTrainer:
         # data parallel: gradients are summed over the ranks before every Adam step.  The critic's largest
         # gradient (the last 2-D stage's weights, 8.4 of 11.1 MB) is complete first in the backward pass and
         # its reduction is started right then, beside the rest of the backward; the remainder follows.
-        self._early = []                      # (name, pending reduction)
+        # The generator step's gradient is reduced layer by layer the same way: each 2-D convolution weight gradient as
+        # its weight-gradient kernel finishes (last layer first), the rest (first layer, BatchNorm parameters, 1-D tower)
+        # after the backward.
+        self._early = []                      # (store, name, pending reduction)
         self.early_names = ("twod_conv_layers.9.weight",)
+        self.early_names_g = tuple(f"twod_conv_layers.{3 * i}.weight" for i in (4, 3, 2, 1))
         self.dist_active, self.sync_bn, self._drain = False, False, False
         if world > 1 or process_group is not None:
             self.attach_process_group(process_group, sync_bn)
@@ -81,6 +85,7 @@ class FusedTrainer:
         self._drain = self.dev.type == "cuda" and dist.is_initialized() and dist.get_backend(process_group) != "nccl"
         # collectives run on "the current stream": a launch tape replays them under the stream they were issued on
         self.eng.grad_ready = lambda name: pgan_tape.call(self._early_reduce, name, on_current_stream=True)
+        self.eng.gen_grad_ready = lambda name: pgan_tape.call(self._early_reduce_g, name, on_current_stream=True)
         self.sync_bn = True if sync_bn is None else bool(sync_bn)
         if self.sync_bn:
             self.eng.bn_sync = lambda part: pgan_tape.call(self._bn_allreduce, part, on_current_stream=True)
@@ -182,13 +187,17 @@ class FusedTrainer:
             torch.cuda.synchronize()
         dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def _early_reduce(self, name: str) -> None:
-        if name in self.early_names:
+    def _early_reduce(self, name: str, store=None, names=None) -> None:
+        store = self.eng.D if store is None else store
+        if name in (self.early_names if names is None else names):
             import torch.distributed as dist
             if self._drain:
                 torch.cuda.synchronize()
-            work = dist.all_reduce(self.eng.D.g[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._early.append((name, work))
+            work = dist.all_reduce(store.g[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._early.append((store, name, work))
+
+    def _early_reduce_g(self, name: str) -> None:
+        self._early_reduce(name, self.eng.G, self.early_names_g)
 
     def _allreduce(self, flat: torch.Tensor) -> None:
         """Sum `flat` (a store's whole gradient buffer) over the ranks and divide by their number; ranges whose
@@ -198,17 +207,18 @@ class FusedTrainer:
         import torch.distributed as dist
         if self._drain:
             torch.cuda.synchronize()
-        store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else None
-        if store is not None and self._early:
-            done = sorted((store.offsets[n], store.offsets[n] + store.p[n].numel()) for n, _ in self._early)
+        store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else self.eng.G
+        mine = [(n, w) for st, n, w in self._early if st is store]
+        if flat.data_ptr() == store.gflat.data_ptr() and mine:
+            done = sorted((store.offsets[n], store.offsets[n] + store.p[n].numel()) for n, _ in mine)
             lo = 0
             for a, b in done + [(flat.numel(), flat.numel())]:
                 if a > lo:
                     dist.all_reduce(flat[lo:a], op=dist.ReduceOp.SUM, group=self.pg)
                 lo = b
-            for _, work in self._early:
+            for _, work in mine:
                 work.wait()
-            self._early = []
+            self._early = [e for e in self._early if e[0] is not store]
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
         if self.world > 1:

@@ -1,7 +1,9 @@
-"""Data-parallel path on the GPU kernels: two processes share the one GPU of the test box (gloo moves the
-CUDA tensors, as RCCL does between GPUs), each with half of the batch.  (Collected after the other GPU tests.)  Reduced gradients, losses and the
-generator's running statistics equal one process at the whole batch: the critic has no batch coupling, the
-generator's BatchNorm layers reduce their per-channel sums over the ranks (src/layers.py:93-108,119-134)."""
+"""Data-parallel path on the GPU kernels: two processes, each with half of the batch -- over RCCL (backend "nccl") on
+two GPUs where the box has them, and sharing the one GPU of a single-GPU box with gloo moving the CUDA tensors.
+(Collected after the other GPU tests.)  Reduced gradients, losses and the generator's running statistics equal one
+process at the whole batch: the critic has no batch coupling, the generator's BatchNorm layers reduce their per-channel
+sums over the ranks (src/layers.py:93-108,119-134).  A third test runs the trainer's own iteration on one rank over
+RCCL (collectives inside the launch tape) against the same iteration without a process group."""
 import os
 import socket
 import sys
@@ -48,15 +50,18 @@ def _load(tr):
     tr.weights_changed()
 
 
-def _worker(rank, world, port, loss, out_dir):
+def _worker(rank, world, port, loss, out_dir, backend="gloo"):
     for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
         sys.path.insert(0, p)
     from pgan_hip import HipOps
     from pgan_trainer import FusedTrainer
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     tr = FusedTrainer(HipOps(dev), B // world, dev, loss=loss, process_group=dist.group.WORLD, rank=rank, world=world)
     assert tr.sync_bn
     _load(tr)
@@ -74,14 +79,17 @@ def _worker(rank, world, port, loss, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("loss", ["gp", "div"])
-def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss):
+def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss, backend):
     from pgan_hip import HipOps
     from pgan_trainer import FusedTrainer
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL between two ranks needs two GPUs")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, loss, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, loss, str(tmp_path), backend), nprocs=2, join=True)
     got = torch.load(tmp_path / "dp.pt", weights_only=True)
     dev = torch.device("cuda", 0)
     tr = FusedTrainer(HipOps(dev), B, dev, loss=loss)
@@ -103,3 +111,48 @@ def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss):
     for k, v in e.Gbuf.p.items():
         assert torch.allclose(got["buf"][k], v.cpu(), rtol=2e-5, atol=1e-6), k
 
+
+
+def _one_rank_worker(rank, port, out_dir):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    rs, rp = orc.synthetic_alignments(64, 9)
+    out = {}
+    for dp in (False, True):
+        tr = FusedTrainer(HipOps(dev), B, dev, critic_iter=2, seed=77)
+        if dp:      # after the trainer, as the CLI and the benchmark do
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            tr.attach_process_group(dist.group.WORLD)
+        _load(tr)
+        tr.set_pool(rs, rp)
+        tr.use_tape = True
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        out[dp] = dict(d=tr.eng.D.flat.clone().cpu(), g=tr.eng.G.flat.clone().cpu(), losses=list(tr.losses()),
+                       buf={k: v.clone().cpu() for k, v in tr.eng.Gbuf.p.items()})
+    torch.save(out, os.path.join(out_dir, "one.pt"))
+    dist.destroy_process_group()
+
+
+def test_trainer_iteration_over_rccl_on_one_rank(tmp_path):
+    """The trainer's whole iteration with every collective of the data-parallel path issued over RCCL (one rank:
+    gradient all-reduces with the per-layer early reductions of both networks, BatchNorm partial-sum all-reduces,
+    all recorded on and replayed from the launch tape) trains like the same iteration without a process group."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_one_rank_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(tmp_path / "one.pt", weights_only=True)
+    a, b = out[False], out[True]
+    lr, steps = 5e-5, 3 * 2
+    for k in ("d", "g"):
+        assert float((a[k] - b[k]).abs().max()) <= 2 * lr * steps, k
+        assert float((a[k] - b[k]).norm() / a[k].norm()) < 1e-3, k
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) <= 1e-2 * max(1.0, abs(x))
