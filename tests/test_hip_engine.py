@@ -11,6 +11,7 @@ from helpers import check_summary, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+GOLDEN_TIGHT = 2e-5    # bound on the reference-made fp32 gradients when no LeakyReLU slope differs from the fp32 oracle's
 
 
 def z_draw(seed, b):
@@ -67,6 +68,17 @@ def check_region_choice(masks, acts):
     return flips
 
 
+def count_flips(masks, acts):
+    """Activations whose LeakyReLU slope in the HIP run differs from the oracle run that recorded `acts`."""
+    names = {"g2d": "g2d.act", "g1d": "g1d.act", "d_main": "d_main2d.act", "d_gp": "d_gp2d.act"}
+    n = 0
+    for k, mk in masks.items():
+        tag, i = k.rsplit(".", 1)
+        h = acts[f"{names[tag]}{i}"].detach()
+        n += int((torch.where(h > 0, 1.0, 0.1).double() != mk).sum())
+    return n
+
+
 def make_engine(hip, B, loss, act, seed):
     from pgan_engine import Engine
     eng = Engine(hip, B, torch.device(DEV), loss=loss, act=act)
@@ -97,11 +109,19 @@ def test_critic_step_vs_reference_golden(hip, fname, loss):
     # Gradients against the reference's fp32 run: a LeakyReLU pre-activation within rounding of 0
     # (expected about once per 2.5e6 activations) may take the other slope in one of the two fp32
     # implementations, which shifts a whole sample's gradient chain by O(1e-2) and the batch
-    # gradient by O(1e-4) norm-wise (single entries by up to 1e-2 of the rms).  This direct
-    # comparison therefore only guards against formula-level errors (5e-3); the 1e-5 bound is
-    # enforced by test_critic_grads_vs_oracle on the same linear region.
+    # gradient by O(1e-4) norm-wise (single entries by up to 1e-2 of the rms).  With millions of
+    # activations per step some always lie that close to the kink (margin ~1e-8 of the rms even at
+    # B = 4), so what is checked is whether a flip HAPPENED: the slope pattern of the HIP run against
+    # that of the fp32 oracle (the reference's own arithmetic).  No flip: the reference's gradients
+    # are held to 2e-5.  Otherwise this direct comparison only guards against formula-level errors
+    # (5e-3) and the 1e-5 bound is enforced by test_critic_grads_vs_oracle on the same linear region.
+    acts = {}
+    orc.critic_grads(dp, gp_, None, rs, rp, z, loss, float(lam), t, "sigmoid", acts=acts)
+    flips = count_flips(engine_masks(eng, "critic"), acts)
+    rtol = GOLDEN_TIGHT if flips == 0 else 5e-3
+    print(f"{fname}: {flips} slope flips against the fp32 oracle -> gradients held to {rtol:g}")
     for k in dp:
-        check_summary(g, f"grad.{k}", eng.D.g[k], rtol=5e-3, what=f"{fname}:")
+        check_summary(g, f"grad.{k}", eng.D.g[k], rtol=rtol, what=f"{fname}:")
 
 
 @pytest.mark.parametrize("loss,act,B", [("gp", "tanh", 8), ("div", "tanh", 8), ("gp", "sigmoid", 64),
@@ -151,8 +171,13 @@ def test_generator_step_vs_reference_golden(hip, act):
     eng.generator_grads(z_draw(seed + 2, B).to(DEV))
     torch.cuda.synchronize()
     assert abs(float(eng.gloss) - g["loss"][0]) <= 2e-5 * max(1.0, abs(g["loss"][0]))
-    for k in gp_:   # direct fp32-vs-fp32 comparison: 5e-3 (see the critic golden test); 1e-5 is enforced below
-        check_summary(g, f"grad.{k}", eng.G.g[k], rtol=5e-3, what=f"gen {act}:")
+    acts = {}
+    orc.generator_grads(dp, gp_, None, z_draw(seed + 2, B), act, acts=acts)
+    flips = count_flips(engine_masks(eng, "generator"), acts)
+    rtol = GOLDEN_TIGHT if flips == 0 else 5e-3     # see the critic golden test; 1e-5 vs fp64 is enforced below
+    print(f"generator {act}: {flips} slope flips against the fp32 oracle -> gradients held to {rtol:g}")
+    for k in gp_:
+        check_summary(g, f"grad.{k}", eng.G.g[k], rtol=rtol, what=f"gen {act}:")
 
 
 @pytest.mark.parametrize("act,B", [("sigmoid", 8), ("tanh", 8), ("sigmoid", 64), ("sigmoid", 1), ("tanh", 3)])
