@@ -21,7 +21,8 @@ extern "C" {
 
 /* ---- k=4, stride=2, pad=1 convolution pair, weight W[Cs][Cl][4][4] between a small side
  * S[N][Cs][hs][hs] and a large side L[N][Cl][2hs][2hs].  Cl > 1: fp32 MFMA implicit GEMM
- * (Cs % 64 == 0, Cl % 64 == 0 for up / % 8 for down and wgrad, hs in {4, 8, 16}); Cl == 1: hs == 32, Cs <= 64. */
+ * (Cs % 64 == 0, Cl % 64 == 0 for up / % 8 for down and wgrad, hs in {4, 8, 16}); Cl == 1: hs == 32 or 64, Cs <= 64.
+ * The bf16-pipe entry points below also take hs == 32 (Cl % 32 == 0): the extra stage of the 128 x 128 network. */
 
 /* Kernel-variant overrides for tuning runs (no counterpart in the reference): "down_kg" = 1|2|4 K groups
  * of the DOWN kernel, "up_mode" = 1 all-phase tiles | 2 phase-split | 3 phase-split + 2 K groups; 0 = auto. */
@@ -180,6 +181,15 @@ int pgan_d1d_bwd(const float* xp, const float* const* params, const float* a1, c
                  const float* coef, const float* w_tail, float* part, int part_ld, const int* offs, float* dxp, int N,
                  hipStream_t st);
 
+/* The same tower on position vectors of length L = 64 or 128 (128: the scaled network for 128 x 128 alignments, which the
+ * reference does not have -- its head is fixed to 64 x 64 inputs, src/layers.py:482): a1 [N][16][L-3], a2 [N][32][L-6],
+ * a3 [N][64][L-9], feat [N][64 (L-9)], dxp [N][1][L]. */
+int pgan_d1d_fwd_len(const float* xp, const float* const* params, float* a1, float* a2, float* a3, float* feat, int N,
+                     int L, hipStream_t st);
+int pgan_d1d_bwd_len(const float* xp, const float* const* params, const float* a1, const float* a2, const float* a3,
+                     const float* coef, const float* w_tail, float* part, int part_ld, const int* offs, float* dxp,
+                     int N, int L, hipStream_t st);
+
 /* ---- generator 1-D tower stages nn.ConvTranspose1d(k4, s2, p1), src/layers.py:122-137: forward
  * (+ fused sigmoid/tanh), input gradient, weight gradient.  y [N][Cs][Ls], x [N][Cl][2 Ls], w [Cs][Cl][4]. */
 int pgan_ct1d_up(const float* y, const float* w, float* x, int N, int Cs, int Cl, int Ls, int act, hipStream_t st);
@@ -215,12 +225,12 @@ int pgan_parse_ms(const char* text, long long len, int rows, int cols, int max_r
  * replacement to out_s / out_p.  state: 4 device ints (head, count, error flag, spare), zeroed by the caller once;
  * slots: B device ints of scratch; picks: NULL, or B device ints with the logical indices to take (0 = oldest) in
  * place of random draws (state[2] is set if one lies outside the buffer).
- * pgan_sample_genotypes: sample_genotypes_bernoulli (src/train_wgan_v2.py:162-192) on p[n][1][64][S]. */
+ * pgan_sample_genotypes: sample_genotypes_bernoulli (src/train_wgan_v2.py:162-192) on p[n][1][rows][S], rows = 64 | 128. */
 int pgan_fakebuf_step(float* buf_s, float* buf_p, int size, int* state, int* slots, const float* new_s,
                       const float* new_p, float* out_s, float* out_p, int B, int Ms, int Mp, unsigned int* rng,
                       const int* picks, hipStream_t st);
-int pgan_sample_genotypes(const float* p, float* out, long long n, int S, unsigned int* rng, int require_variation,
-                          hipStream_t st);
+int pgan_sample_genotypes(const float* p, float* out, long long n, int rows, int S, unsigned int* rng,
+                          int require_variation, hipStream_t st);
 
 /* ---- one step as a hipGraph (the reference launches its step op by op from Python, src/train_wgan_v2.py:534-634):
  * begin capture on st, enqueue the step once through the entry points above (side streams join st through events),

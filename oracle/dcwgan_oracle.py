@@ -46,28 +46,39 @@ BN_MOMENTUM = 0.1
 # parameter tables (names/shapes == the reference modules' state_dict, layers.py:91-140,439-482)
 # ----------------------------------------------------------------------------------------
 
+def net_dims(data: int = DATA, latent: int = LATENT):
+    """Channel tables for `data` x `data` alignments.  64: the reference's modules.  128: the scaled networks the
+    build defines (PARITY UNPINNED for that size: the reference has no 128 x 128 model -- its discriminator head is
+    Linear(11712, 1), layers.py:482, and its generator always emits 64 x 64) -- one more stride-2 stage at the
+    large end of each 2-D tower and of the generator's 1-D tower, same layer types and hyper-parameters."""
+    if data == 64:
+        return dict(d2c=[1, 64, 128, 256, 512], g2c=[latent, 512, 256, 128, 64, 1],
+                    g1c=[latent, latent // 2, latent // 4, latent // 8, latent // 16, 1])
+    if data == 128:
+        return dict(d2c=[1, 32, 64, 128, 256, 512], g2c=[latent, 512, 256, 128, 64, 32, 1],
+                    g1c=[latent, latent // 2, latent // 4, latent // 8, latent // 16, latent // 32, 1])
+    raise ValueError(data)
+
+
 def gen_param_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [latent, data * 8, data * 4, data * 2, data, 1]
-    for i in range(5):
-        s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i], ch2[i + 1], 4, 4)
-        if i < 4:
-            s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
-            s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
-    ch1 = [latent, latent // 2, latent // 4, latent // 8, latent // 16, 1]
-    for i in range(5):
-        s[f"oned_conv_layers.{3 * i}.weight"] = (ch1[i], ch1[i + 1], 4)
-        if i < 4:
-            s[f"oned_conv_layers.{3 * i + 1}.weight"] = (ch1[i + 1],)
-            s[f"oned_conv_layers.{3 * i + 1}.bias"] = (ch1[i + 1],)
-    return s
+    dm = net_dims(data, latent)
+    for tower, ch, k in (("twod_conv_layers", dm["g2c"], (4, 4)), ("oned_conv_layers", dm["g1c"], (4,))):
+        n = len(ch) - 1
+        for i in range(n):
+            s[f"{tower}.{3 * i}.weight"] = (ch[i], ch[i + 1]) + k
+            if i < n - 1:
+                s[f"{tower}.{3 * i + 1}.weight"] = (ch[i + 1],)
+                s[f"{tower}.{3 * i + 1}.bias"] = (ch[i + 1],)
+    # the reference module registers the 2-D tower's layers first, then the 1-D tower's, layer by layer
+    order = [k for k in s if k.startswith("twod")] + [k for k in s if k.startswith("oned")]
+    return {k: s[k] for k in order}
 
 
 def gen_buffer_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [data * 8, data * 4, data * 2, data]
-    ch1 = [latent // 2, latent // 4, latent // 8, latent // 16]
-    for tower, chs in (("twod_conv_layers", ch2), ("oned_conv_layers", ch1)):
+    dm = net_dims(data, latent)
+    for tower, chs in (("twod_conv_layers", dm["g2c"][1:-1]), ("oned_conv_layers", dm["g1c"][1:-1])):
         for i, c in enumerate(chs):
             s[f"{tower}.{3 * i + 1}.running_mean"] = (c,)
             s[f"{tower}.{3 * i + 1}.running_var"] = (c,)
@@ -77,8 +88,8 @@ def gen_buffer_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple
 
 def disc_param_shapes(data: int = DATA) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [1, data, data * 2, data * 4, data * 8]
-    for i in range(4):
+    ch2 = net_dims(data)["d2c"]
+    for i in range(len(ch2) - 1):
         s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i + 1], ch2[i], 4, 4)
         s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
         s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
@@ -88,9 +99,17 @@ def disc_param_shapes(data: int = DATA) -> Dict[str, Tuple[int, ...]]:
         s[f"oned_conv_layers.{3 * i}.bias"] = (ch1[i + 1],)
         s[f"oned_conv_layers.{3 * i + 1}.weight"] = (ch1[i + 1],)
         s[f"oned_conv_layers.{3 * i + 1}.bias"] = (ch1[i + 1],)
-    s["out.weight"] = (1, 11712)
+    s["out.weight"] = (1, ch2[-1] * 16 + 64 * (data - 9))
     s["out.bias"] = (1,)
     return s
+
+
+def _n_layers(p: ParamDict, tower: str) -> int:
+    """Convolution layers of a tower, from the parameter names present."""
+    n = 0
+    while f"{tower}.{3 * n}.weight" in p:
+        n += 1
+    return n
 
 
 def _is_norm_scale(name: str, shape: Tuple[int, ...]) -> bool:
@@ -178,21 +197,23 @@ def gen_forward(p: ParamDict, buf: Optional[ParamDict], z: Tensor, act: str = "s
         return F.batch_norm(x, rm, rv, p[name + ".weight"], p[name + ".bias"], True, BN_MOMENTUM, BN_EPS)
 
     x = z
-    for i in range(5):
+    n2 = _n_layers(p, "twod_conv_layers")
+    for i in range(n2):
         w = p[f"twod_conv_layers.{3 * i}.weight"]
         x = F.conv_transpose2d(x, w, None, stride=1 if i == 0 else 2, padding=0 if i == 0 else 1)
         if acts is not None:
             acts[f"g2d.conv{i}"] = x
-        if i < 4:
+        if i < n2 - 1:
             x = _lrelu(bn(x, "twod_conv_layers", 3 * i + 1), f"g2d.{i}", masks)
             if acts is not None:
                 acts[f"g2d.act{i}"] = x
     xs = final(x)
     y = z[:, :, :, 0]
-    for i in range(5):
+    n1 = _n_layers(p, "oned_conv_layers")
+    for i in range(n1):
         w = p[f"oned_conv_layers.{3 * i}.weight"]
         y = F.conv_transpose1d(y, w, None, stride=1 if i == 0 else 2, padding=0 if i == 0 else 1)
-        if i < 4:
+        if i < n1 - 1:
             y = _lrelu(bn(y, "oned_conv_layers", 3 * i + 1), f"g1d.{i}", masks)
             if acts is not None:
                 acts[f"g1d.act{i}"] = y
@@ -205,7 +226,7 @@ def disc_forward(p: ParamDict, xs: Tensor, xp: Tensor, acts: Optional[Dict[str, 
     """layers.py:487-493: 4x[Conv2d k4 s2 p1 no bias, GroupNorm(1,C), LeakyReLU 0.1], flatten;
     3x[Conv1d k4 bias, GroupNorm(1,C), LeakyReLU], flatten; cat; Linear(11712,1)."""
     x = xs
-    for i in range(4):
+    for i in range(_n_layers(p, "twod_conv_layers")):
         x = F.conv2d(x, p[f"twod_conv_layers.{3 * i}.weight"], None, stride=2, padding=1)
         if acts is not None:
             acts[f"d2d.conv{i}"] = x

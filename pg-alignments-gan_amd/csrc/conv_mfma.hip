@@ -1104,8 +1104,9 @@ int pgan_set_option(const char* name, int value) {
 int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
     if (Cl == 1) {
-        if (hs != 32 || Cs > 64) return PGAN_EINVAL;
-        conv_down_c1_kernel<32><<<N * (32 / 8), 256, 0, st>>>(L, W, S, N, Cs);
+        if ((hs != 32 && hs != 64) || Cs > 64) return PGAN_EINVAL;
+        if (hs == 32) conv_down_c1_kernel<32><<<N * (32 / 8), 256, 0, st>>>(L, W, S, N, Cs);
+        else conv_down_c1_kernel<64><<<N * (64 / 4), 256, 0, st>>>(L, W, S, N, Cs);
         return pgan_launch_status();
     }
     switch (hs) {
@@ -1121,8 +1122,9 @@ int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int 
 int pgan_conv_up(const float* S, const float* W, float* L, int N, int Cs, int Cl, int hs, int act, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
     if (Cl == 1) {
-        if (hs != 32 || Cs > 64 || Cs % 8) return PGAN_EINVAL;
-        conv_up_c1_kernel<32><<<N * (32 / 4), 1024, 0, st>>>(S, W, L, N, Cs, act);
+        if ((hs != 32 && hs != 64) || Cs > 64 || Cs % 8) return PGAN_EINVAL;
+        if (hs == 32) conv_up_c1_kernel<32><<<N * (32 / 4), 1024, 0, st>>>(S, W, L, N, Cs, act);
+        else conv_up_c1_kernel<64><<<N * (64 / 4), 1024, 0, st>>>(S, W, L, N, Cs, act);
         return pgan_launch_status();
     }
     if (act != 0) return PGAN_EINVAL;
@@ -1152,8 +1154,9 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
                     int hs, int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
     if (Cl == 1) {
-        if (hs != 32 || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
-        conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
+        if ((hs != 32 && hs != 64) || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
+        if (hs == 32) conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
+        else conv_wgrad_c1_kernel<64><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
         rows_sum_kernel<<<(Cs * 16 + 31) / 32, 256, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, accumulate);
         return pgan_launch_status();
     }

@@ -442,10 +442,11 @@ struct WgGeom {
     // HS >= 8: kw planes
     static constexpr int PRR = 2 * R + 2;                            // raw rows per chunk
     static constexpr int SR = WS * 2;                                // bytes per plane row (WS bf16)
-    static constexpr int KWB = PRR * SR + ((PRR * SR / 16) % 2 == 0 && HS == 16 ? 16 : 0);
+    static constexpr int KWB = PRR * SR + ((PRR * SR / 16) % 2 == 0 && HS >= 16 ? 16 : 0);
     static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB;        // bytes per (segment,) channel
     static constexpr int BPL = (HS == 4) ? SEG * CLB * CHB : CLB * CHB;
     static constexpr int LDS_BYTES = 3 * APL + 3 * BPL;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
     // staging items of the L side
     static constexpr int NIB = (HS == 4) ? SEG * CLB * 4 * 4 : CLB * PRR * (WS / 2);
     static constexpr int NQB = (NIB + 255) / 256;
@@ -588,12 +589,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int cl_l = wn * 4 + tn * 2 + (j >> 4), kh = (j >> 2) & 3, kw = j & 3;
-        if constexpr (HS == 16) bbase[tn] = cl_l * G::CHB + kw * G::KWB + kh * G::SR + h * 16;
+        if constexpr (HS >= 16) bbase[tn] = cl_l * G::CHB + kw * G::KWB + kh * G::SR + h * 16;
         else if constexpr (HS == 8) bbase[tn] = cl_l * G::CHB + kw * G::KWB + (2 * h + kh) * G::SR;
         else bbase[tn] = (cl_l * 16 + (j & 15)) * 32 + (h ^ (kh & 1)) * 16;
     }
-    // byte advance of the B fragment per K step (16 pixels)
-    constexpr int BSTEP = (HS == 16) ? 2 * G::SR : (HS == 8 ? 4 * G::SR : CLB * G::CHB);
+    // byte offset of the B fragment of K step s (16 consecutive pixels: half a row at HS = 32, one row at 16, two at 8,
+    // a whole sample at 4)
+    auto bstep = [](int s) constexpr {
+        return (HS == 32) ? (s >> 1) * 2 * G::SR + (s & 1) * 32
+                          : s * ((HS == 16) ? 2 * G::SR : (HS == 8 ? 4 * G::SR : CLB * G::CHB));
+    };
     f32x16 acc[2], acl[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * G::BPL + bbase[tn] + s * BSTEP);
+                    bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * G::BPL + bbase[tn] + bstep(s));
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) mfma_x3(a, bo[tn], acc[tn], acl[tn]);
         }
@@ -767,6 +772,7 @@ int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int C
         case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st);
         case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st);
         case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st);
+        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st);
         default: return PGAN_EINVAL;
     }
 }
@@ -779,6 +785,7 @@ int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs,
         case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st);
         case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st);
         case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st);
+        case 32: return launch_up<32>(S, wp, L, N, Cs, Cl, st);
         default: return PGAN_EINVAL;
     }
 }
@@ -790,6 +797,7 @@ long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs) {
         case 4: ns = wgrad_x3_splits<4>(N, Cs, Cl); break;
         case 8: ns = wgrad_x3_splits<8>(N, Cs, Cl); break;
         case 16: ns = wgrad_x3_splits<16>(N, Cs, Cl); break;
+        case 32: ns = wgrad_x3_splits<32>(N, Cs, Cl); break;
         default: return -1;
     }
     return (long long)ns * Cs * Cl * 16;
@@ -803,6 +811,7 @@ int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, lon
         case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
         case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
         case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 32: return launch_wgrad<32>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
         default: return PGAN_EINVAL;
     }
 }

@@ -104,54 +104,64 @@ __global__ void fakebuf_gather_kernel(const float* __restrict__ buf_s, const flo
 }
 
 // ---------------- genotype sampling ----------------
-// One thread per (alignment, column): 64 Bernoulli draws down the column (u < p, as torch.bernoulli); a column that
+// One thread per (alignment, column): ROWS Bernoulli draws down the column (u < p, as torch.bernoulli); a column that
 // came out monomorphic is drawn again and one individual, picked in proportion to its probability of carrying the
-// missing allele (+1e-7), is set to it.  CALLS Philox calls are reserved per column (64 + 64 + 1 uniforms).
-constexpr int GT_ROWS = 64, GT_CALLS = 36;
+// missing allele (+1e-7), is set to it.  GT_CALLS Philox calls are reserved per column (2 ROWS + 1 uniforms at most).
+constexpr int GT_CALLS = 68;
 
+template <int ROWS>
 __global__ __launch_bounds__(256) void sample_genotypes_kernel(const float* __restrict__ p, float* __restrict__ out,
                                                                int64_t ncol, int S, const uint32_t* __restrict__ rng,
                                                                int require_variation) {
+    constexpr int W = ROWS / 64;
+    static_assert(ROWS % 64 == 0 && 2 * (ROWS / 4) + 1 <= GT_CALLS, "column length");
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ncol) return;
     const int64_t n = t / S;
     const int j = (int)(t % S);
-    const float* col = p + n * GT_ROWS * S + j;
-    float* ocol = out + n * GT_ROWS * S + j;
+    const float* col = p + n * ROWS * S + j;
+    float* ocol = out + n * ROWS * S + j;
     const uint64_t base = philox_offset(rng) + (uint64_t)t * GT_CALLS;
     const uint32_t k0 = rng[0], k1 = rng[1];
     uint32_t c[4];
+    uint64_t m[W];
     auto draw_column = [&](int call0) {
-        uint64_t m = 0;
-        for (int i = 0; i < GT_ROWS; ++i) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) m[w] = 0;
+        for (int i = 0; i < ROWS; ++i) {
             if ((i & 3) == 0) philox4(base + call0 + (i >> 2), k0, k1, c);
             const float u = (c[i & 3] >> 8) * (1.0f / 16777216.0f);
-            if (u < col[(int64_t)i * S]) m |= 1ull << i;
+            if (u < col[(int64_t)i * S]) m[i >> 6] |= 1ull << (i & 63);
         }
-        return m;
     };
-    uint64_t m = draw_column(0);
-    if (require_variation && (m == 0ull || m == ~0ull)) {
-        const bool have = m != 0ull;                       // the allele every individual carries
+    auto uniform = [&](uint64_t v) {
+        bool all = true;
+#pragma unroll
+        for (int w = 0; w < W; ++w) all = all && m[w] == v;
+        return all;
+    };
+    draw_column(0);
+    if (require_variation && (uniform(0ull) || uniform(~0ull))) {
+        const bool have = m[0] != 0ull;                    // the allele every individual carries
         double total = 0.0;
-        for (int i = 0; i < GT_ROWS; ++i) {
+        for (int i = 0; i < ROWS; ++i) {
             const float q = col[(int64_t)i * S];
             total += (double)(have ? 1.f - q : q) + 1e-7;
         }
-        m = draw_column(16);
-        philox4(base + 32, k0, k1, c);
+        draw_column(ROWS / 4);
+        philox4(base + 2 * (ROWS / 4), k0, k1, c);
         const double target = (double)((c[0] >> 8) * (1.0f / 16777216.0f)) * total;
         double acc = 0.0;
-        int pick = GT_ROWS - 1;
-        for (int i = 0; i < GT_ROWS; ++i) {
+        int pick = ROWS - 1;
+        for (int i = 0; i < ROWS; ++i) {
             const float q = col[(int64_t)i * S];
             acc += (double)(have ? 1.f - q : q) + 1e-7;
             if (target < acc) { pick = i; break; }
         }
-        if (have) m &= ~(1ull << pick);
-        else m |= 1ull << pick;
+        if (have) m[pick >> 6] &= ~(1ull << (pick & 63));
+        else m[pick >> 6] |= 1ull << (pick & 63);
     }
-    for (int i = 0; i < GT_ROWS; ++i) ocol[(int64_t)i * S] = (float)((m >> i) & 1ull);
+    for (int i = 0; i < ROWS; ++i) ocol[(int64_t)i * S] = (float)((m[i >> 6] >> (i & 63)) & 1ull);
 }
 __global__ void genotype_rng_advance_kernel(uint32_t* rng, uint64_t calls) { philox_bump(rng, calls); }
 
@@ -176,12 +186,15 @@ int pgan_fakebuf_step(float* buf_s, float* buf_p, int size, int* state, int* slo
     return pgan_launch_status();
 }
 
-// out[n][1][64][S] ~ Bernoulli(p) with every column polymorphic when require_variation != 0 (see the kernel).
-int pgan_sample_genotypes(const float* p, float* out, long long n, int S, unsigned int* rng, int require_variation,
-                          hipStream_t st) {
-    if (n <= 0 || S <= 0 || !p || !out || !rng) return PGAN_EINVAL;
+// out[n][1][rows][S] ~ Bernoulli(p) with every column polymorphic when require_variation != 0 (see the kernel);
+// rows = 64 or 128 individuals.
+int pgan_sample_genotypes(const float* p, float* out, long long n, int rows, int S, unsigned int* rng,
+                          int require_variation, hipStream_t st) {
+    if (n <= 0 || S <= 0 || !p || !out || !rng || (rows != 64 && rows != 128)) return PGAN_EINVAL;
     const int64_t ncol = (int64_t)n * S;
-    sample_genotypes_kernel<<<(unsigned)((ncol + 255) / 256), 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
+    const unsigned grid = (unsigned)((ncol + 255) / 256);
+    if (rows == 64) sample_genotypes_kernel<64><<<grid, 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
+    else sample_genotypes_kernel<128><<<grid, 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
     genotype_rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)ncol * GT_CALLS);
     return pgan_launch_status();
 }

@@ -9,7 +9,8 @@
 namespace {
 
 constexpr int D1_C0 = 1, D1_C1 = 16, D1_C2 = 32, D1_C3 = 64;
-constexpr int D1_L0 = 64, D1_L1 = 61, D1_L2 = 58, D1_L3 = 55;
+// position vectors of length L0 = 64 (the reference's alignments) or 128 (the scaled network); every k=4 valid
+// convolution shortens them by 3
 
 struct D1Params {
     const float* cw[3];
@@ -50,9 +51,11 @@ __device__ __forceinline__ void gn_stats(const float* a, int M, double* sh, floa
     r = (float)(1.0 / sqrt(var + (double)PGAN_EPS));
 }
 
+template <int D1_L0>
 __global__ __launch_bounds__(1024) void d1d_fwd_kernel(const float* __restrict__ xp, D1Params P, float* __restrict__ a1s,
                                                       float* __restrict__ a2s, float* __restrict__ a3s,
                                                       float* __restrict__ feat) {
+    constexpr int D1_L1 = D1_L0 - 3, D1_L2 = D1_L0 - 6, D1_L3 = D1_L0 - 9;
     __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], a3[D1_C3 * D1_L3];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -179,20 +182,27 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
     }
 }
 
+// L0 = 128: the last stage's weights (32 KB) stay in global memory -- with them the kernel's LDS would exceed a CU's.
+template <int D1_L0>
 __global__ __launch_bounds__(512) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
                                                       const float* __restrict__ a1s, const float* __restrict__ a2s,
                                                       const float* __restrict__ a3s, const float* __restrict__ coef,
                                                       const float* __restrict__ w_tail, float* __restrict__ part,
                                                       int part_ld, D1Offsets off, float* __restrict__ dxp) {
+    constexpr int D1_L1 = D1_L0 - 3, D1_L2 = D1_L0 - 6, D1_L3 = D1_L0 - 9;
+    constexpr bool W3_LDS = D1_L0 <= 64;
     __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], h1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], h2[D1_C2 * D1_L2],
         a3[D1_C3 * D1_L3], g3[D1_C3 * D1_L3], g2[D1_C2 * D1_L2], g1[D1_C1 * D1_L1], g0[D1_L0];
-    __shared__ __attribute__((aligned(16))) float w1s[D1_C1 * D1_C0 * 4], w2s[D1_C2 * D1_C1 * 4], w3s[D1_C3 * D1_C2 * 4];
+    __shared__ __attribute__((aligned(16))) float w1s[D1_C1 * D1_C0 * 4], w2s[D1_C2 * D1_C1 * 4],
+        w3buf[W3_LDS ? D1_C3 * D1_C2 * 4 : 4];
     const int n = blockIdx.x, tid = threadIdx.x;
     float* prow = part ? part + (int64_t)n * part_ld : nullptr;
     for (int i = tid; i < D1_C1 * D1_C0 * 4; i += blockDim.x) w1s[i] = P.cw[0][i];
     for (int i = tid; i < D1_C2 * D1_C1 * 4; i += blockDim.x) w2s[i] = P.cw[1][i];
-    for (int i = tid; i < D1_C3 * D1_C2 * 4; i += blockDim.x) w3s[i] = P.cw[2][i];
+    if constexpr (W3_LDS)
+        for (int i = tid; i < D1_C3 * D1_C2 * 4; i += blockDim.x) w3buf[i] = P.cw[2][i];
+    const float* w3s = W3_LDS ? w3buf : P.cw[2];
     for (int i = tid; i < D1_L0; i += blockDim.x) x0[i] = xp[(int64_t)n * D1_L0 + i];
     for (int i = tid; i < D1_C1 * D1_L1; i += blockDim.x) a1[i] = a1s[(int64_t)n * D1_C1 * D1_L1 + i];
     for (int i = tid; i < D1_C2 * D1_L2; i += blockDim.x) a2[i] = a2s[(int64_t)n * D1_C2 * D1_L2 + i];
@@ -375,25 +385,38 @@ D1Params make_params(const float* const* p) {
 extern "C" {
 
 // params: 12 device pointers in the order cw0 cb0 gw0 gb0 cw1 cb1 gw1 gb1 cw2 cb2 gw2 gb2.
-// xp [N,1,64] -> conv outputs a1 [N,16,61], a2 [N,32,58], a3 [N,64,55] (saved for backward) and
-// feat [N, 64*55].
+// xp [N,1,L] -> conv outputs a1 [N,16,L-3], a2 [N,32,L-6], a3 [N,64,L-9] (saved for backward) and
+// feat [N, 64*(L-9)]; L = 64 or 128.
+int pgan_d1d_fwd_len(const float* xp, const float* const* params, float* a1, float* a2, float* a3, float* feat, int N,
+                     int L, hipStream_t st) {
+    if (N <= 0 || (L != 64 && L != 128)) return PGAN_EINVAL;
+    if (L == 64) d1d_fwd_kernel<64><<<N, 1024, 0, st>>>(xp, make_params(params), a1, a2, a3, feat);
+    else d1d_fwd_kernel<128><<<N, 1024, 0, st>>>(xp, make_params(params), a1, a2, a3, feat);
+    return pgan_launch_status();
+}
 int pgan_d1d_fwd(const float* xp, const float* const* params, float* a1, float* a2, float* a3, float* feat, int N,
                  hipStream_t st) {
-    if (N <= 0) return PGAN_EINVAL;
-    d1d_fwd_kernel<<<N, 1024, 0, st>>>(xp, make_params(params), a1, a2, a3, feat);
-    return pgan_launch_status();
+    return pgan_d1d_fwd_len(xp, params, a1, a2, a3, feat, N, 64, st);
 }
 
 // Backward of sum_n coef[n] <w_tail, feat[n]>.  part (may be null): [N, part_ld] per-sample parameter
-// gradient rows, the 12 tensors placed at offs[0..11] (same order as params); dxp (may be null): [N,1,64].
+// gradient rows, the 12 tensors placed at offs[0..11] (same order as params); dxp (may be null): [N,1,L].
+int pgan_d1d_bwd_len(const float* xp, const float* const* params, const float* a1, const float* a2, const float* a3,
+                     const float* coef, const float* w_tail, float* part, int part_ld, const int* offs, float* dxp,
+                     int N, int L, hipStream_t st) {
+    if (N <= 0 || (part && !offs) || (L != 64 && L != 128)) return PGAN_EINVAL;
+    D1Offsets o;
+    for (int i = 0; i < 12; ++i) o.o[i] = offs ? offs[i] : 0;
+    if (L == 64)
+        d1d_bwd_kernel<64><<<N, 512, 0, st>>>(xp, make_params(params), a1, a2, a3, coef, w_tail, part, part_ld, o, dxp);
+    else
+        d1d_bwd_kernel<128><<<N, 512, 0, st>>>(xp, make_params(params), a1, a2, a3, coef, w_tail, part, part_ld, o, dxp);
+    return pgan_launch_status();
+}
 int pgan_d1d_bwd(const float* xp, const float* const* params, const float* a1, const float* a2, const float* a3,
                  const float* coef, const float* w_tail, float* part, int part_ld, const int* offs, float* dxp, int N,
                  hipStream_t st) {
-    if (N <= 0 || (part && !offs)) return PGAN_EINVAL;
-    D1Offsets o;
-    for (int i = 0; i < 12; ++i) o.o[i] = offs ? offs[i] : 0;
-    d1d_bwd_kernel<<<N, 512, 0, st>>>(xp, make_params(params), a1, a2, a3, coef, w_tail, part, part_ld, o, dxp);
-    return pgan_launch_status();
+    return pgan_d1d_bwd_len(xp, params, a1, a2, a3, coef, w_tail, part, part_ld, offs, dxp, N, 64, st);
 }
 
 int pgan_ct1d_up(const float* y, const float* w, float* x, int N, int Cs, int Cl, int Ls, int act, hipStream_t st) {

@@ -40,29 +40,51 @@ FEAT2 = 512 * 16
 FEAT1 = 64 * 55
 
 
+def net_dims(data: int = DATA, latent: int = LATENT) -> Dict[str, Tuple[int, ...]]:
+    """Layer tables of the two networks for `data` x `data` alignments.  64: the reference's networks
+    (layers.py:91-140,439-482).  128: the scaled networks of this package (the reference has none: its
+    discriminator head is hard-wired to 64 x 64 inputs, layers.py:482) -- one more stride-2 stage at the
+    large end of each 2-D tower (discriminator 1->32->64->128->256->512 over 128->...->4, generator
+    ...->64->32->1 over ...->32->64->128) and of the generator's 1-D tower; the discriminator's 1-D tower keeps
+    its three k=4 convolutions on the longer position vector."""
+    if data == 64:
+        d2c, g2c = (1, 64, 128, 256, 512), (latent, 512, 256, 128, 64, 1)
+        g1c = (latent, latent // 2, latent // 4, latent // 8, latent // 16, 1)
+    elif data == 128:
+        d2c, g2c = (1, 32, 64, 128, 256, 512), (latent, 512, 256, 128, 64, 32, 1)
+        g1c = (latent, latent // 2, latent // 4, latent // 8, latent // 16, latent // 32, 1)
+    else:
+        raise ValueError(f"alignments of {data} x {data} are not supported (64 or 128)")
+    ns = len(d2c) - 1
+    d2h = tuple(data >> k for k in range(ns + 1))
+    g2h = (1,) + tuple(4 << k for k in range(len(g2c) - 1))
+    return dict(d2c=d2c, d2h=d2h, g2c=g2c, g2h=g2h, g1c=g1c, g1l=g2h, d1c=D1_CH,
+                d1l=(data, data - 3, data - 6, data - 9), feat2=d2c[-1] * d2h[-1] ** 2, feat1=64 * (data - 9))
+
+
 def gen_param_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
     """state_dict entries of DC_Generator_Leaky_{Sig,Tan} (layers.py:91-140), parameters only."""
+    dm = net_dims(data, latent)
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [latent, data * 8, data * 4, data * 2, data, 1]
-    ch1 = [latent, latent // 2, latent // 4, latent // 8, latent // 16, 1]
-    for i in range(5):
+    ch2, ch1 = dm["g2c"], dm["g1c"]
+    n = len(ch2) - 1
+    for i in range(n):
         s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i], ch2[i + 1], 4, 4)
-        if i < 4:
+        if i < n - 1:
             s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
             s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
-    for i in range(5):
+    for i in range(n):
         s[f"oned_conv_layers.{3 * i}.weight"] = (ch1[i], ch1[i + 1], 4)
-        if i < 4:
+        if i < n - 1:
             s[f"oned_conv_layers.{3 * i + 1}.weight"] = (ch1[i + 1],)
             s[f"oned_conv_layers.{3 * i + 1}.bias"] = (ch1[i + 1],)
     return s
 
 
 def gen_buffer_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple[int, ...]]:
+    dm = net_dims(data, latent)
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [data * 8, data * 4, data * 2, data]
-    ch1 = [latent // 2, latent // 4, latent // 8, latent // 16]
-    for tower, chs in (("twod_conv_layers", ch2), ("oned_conv_layers", ch1)):
+    for tower, chs in (("twod_conv_layers", dm["g2c"][1:-1]), ("oned_conv_layers", dm["g1c"][1:-1])):
         for i, c in enumerate(chs):
             s[f"{tower}.{3 * i + 1}.running_mean"] = (c,)
             s[f"{tower}.{3 * i + 1}.running_var"] = (c,)
@@ -71,9 +93,10 @@ def gen_buffer_shapes(latent: int = LATENT, data: int = DATA) -> Dict[str, Tuple
 
 def disc_param_shapes(data: int = DATA) -> Dict[str, Tuple[int, ...]]:
     """state_dict entries of DC_Discriminator (layers.py:439-482)."""
+    dm = net_dims(data)
     s: Dict[str, Tuple[int, ...]] = {}
-    ch2 = [1, data, data * 2, data * 4, data * 8]
-    for i in range(4):
+    ch2 = dm["d2c"]
+    for i in range(len(ch2) - 1):
         s[f"twod_conv_layers.{3 * i}.weight"] = (ch2[i + 1], ch2[i], 4, 4)
         s[f"twod_conv_layers.{3 * i + 1}.weight"] = (ch2[i + 1],)
         s[f"twod_conv_layers.{3 * i + 1}.bias"] = (ch2[i + 1],)
@@ -82,7 +105,7 @@ def disc_param_shapes(data: int = DATA) -> Dict[str, Tuple[int, ...]]:
         s[f"oned_conv_layers.{3 * i}.bias"] = (D1_CH[i + 1],)
         s[f"oned_conv_layers.{3 * i + 1}.weight"] = (D1_CH[i + 1],)
         s[f"oned_conv_layers.{3 * i + 1}.bias"] = (D1_CH[i + 1],)
-    s["out.weight"] = (1, FEAT2 + FEAT1)
+    s["out.weight"] = (1, dm["feat2"] + dm["feat1"])
     s["out.bias"] = (1,)
     return s
 
@@ -112,6 +135,7 @@ class FlatStore:
             self.m = self._views(self.mflat)
             self.v = self._views(self.vflat)
         self.step = 0
+        self.on_load = []       # callables run after load(): holders of derived copies of the weights (prepared planes)
 
     def _views(self, flat):
         out = {}
@@ -125,6 +149,8 @@ class FlatStore:
     def load(self, params: Dict[str, torch.Tensor]) -> None:
         for k, v in self.p.items():
             v.copy_(params[k].to(v.device, torch.float32))
+        for fn in self.on_load:
+            fn()
 
 
 class SideStream:
@@ -177,7 +203,7 @@ class Engine:
                  latent: int = LATENT, lr_d: float = 5e-5, lr_g: float = 5e-5,
                  betas: Tuple[float, float] = (0.5, 0.999), eps: float = 1e-8,
                  g_store: Optional["FlatStore"] = None, g_buffers: Optional["FlatStore"] = None,
-                 d_store: Optional["FlatStore"] = None, generator_only: bool = False):
+                 d_store: Optional["FlatStore"] = None, generator_only: bool = False, data: int = DATA):
         """generator_only: no discriminator workspace (an engine that only runs generator forwards / backwards, e.g.
         the 1000-sample plotting forward of the trainer)."""
         if loss not in ("gp", "div"):
@@ -185,6 +211,11 @@ class Engine:
         if act not in ("sigmoid", "tanh"):
             raise ValueError(f"act must be 'sigmoid' or 'tanh', got {act!r}")
         self.ops, self.B, self.dev = ops, int(batch), device
+        self.data = int(data)
+        dm = self.dims = net_dims(self.data, int(latent))
+        self.d2c, self.d2h, self.nS = dm["d2c"], dm["d2h"], len(dm["d2c"]) - 1
+        self.nG = len(dm["g2c"]) - 2                      # BatchNorm stages of each generator tower
+        self.feat2, self.feat1 = dm["feat2"], dm["feat1"]
         self.loss, self.act, self.lam, self.latent = loss, act, float(lam), int(latent)
         self.act_id = 1 if act == "sigmoid" else 2
         self.lr_d, self.lr_g, self.betas, self.eps = lr_d, lr_g, betas, eps
@@ -199,18 +230,26 @@ class Engine:
             # the last 2-D stage's weights (3/4 of the discriminator) sit at the end of the flat buffers: their
             # gradient is complete first in a backward pass and is reduced on its own in data-parallel runs,
             # the rest then being one contiguous range
-            shapes = disc_param_shapes()
-            shapes["twod_conv_layers.9.weight"] = shapes.pop("twod_conv_layers.9.weight")
+            shapes = disc_param_shapes(self.data)
+            last = f"twod_conv_layers.{3 * (self.nS - 1)}.weight"
+            shapes[last] = shapes.pop(last)
             d_store = FlatStore(shapes, device)
         self.D = d_store
-        self.G = g_store if g_store is not None else FlatStore(gen_param_shapes(latent), device)
+        self.G = g_store if g_store is not None else FlatStore(gen_param_shapes(latent, self.data), device)
         if g_buffers is not None:
             self.Gbuf = g_buffers
         else:
-            self.Gbuf = FlatStore(gen_buffer_shapes(latent), device, with_opt=False)
+            self.Gbuf = FlatStore(gen_buffer_shapes(latent, self.data), device, with_opt=False)
             for k, v in self.Gbuf.p.items():
                 if k.endswith("running_var"):
                     v.fill_(1.0)
+        # Prepared copies of convolution weights are cached by the op backend under the weights' address: a new engine's
+        # buffers can sit where a freed engine's did, and load() rewrites them in place -- both make cached copies stale.
+        stale = getattr(ops, "invalidate_weight_planes", None)
+        if stale is not None:
+            for st in (self.D, self.G):
+                stale(st.flat)
+                st.on_load.append(lambda st=st: stale(st.flat))
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
         # data parallel with batch statistics over all ranks' samples: bn_sync(partial sums, float64) adds them over
         # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch
@@ -242,29 +281,36 @@ class Engine:
         NPl = self.NP
         if generator_only:
             NT = B = NPl = 0        # zero-sized discriminator buffers
-        # ---- discriminator workspace: index k = 1..4 is the k-th conv stage, 0 the input ----
-        self.X0 = torch.zeros(NT, 1, 64, 64, **f)        # sites: primal slots then v (tangent input)
-        self.P0 = torch.zeros(2 * B, 1, 64, **f)         # positions of real | fake
-        self.dA = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
-        self.dH = [self.X0] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
-        self.dU = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
-        self.dJ = [None] + [torch.zeros(NT, D2_CH[k], D2_HW[k], D2_HW[k], **f) for k in range(1, 5)]
-        self.dStat = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]    # mu, rstd
-        self.dStatB = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(w), mean(w xhat)
-        self.dStatT = [None] + [torch.zeros(NT, 2, **f) for _ in range(4)]   # mean(t), mean(xhat t)
+        # ---- discriminator workspace: index k = 1..nS is the k-th conv stage, 0 the input ----
+        S, nS, d2c, d2h = self.data, self.nS, self.d2c, self.d2h
+        stage = lambda n: [None] + [torch.zeros(n, d2c[k], d2h[k], d2h[k], **f) for k in range(1, nS + 1)]
+        self.X0 = torch.zeros(NT, 1, S, S, **f)          # sites: primal slots then v (tangent input)
+        self.P0 = torch.zeros(2 * B, 1, S, **f)          # positions of real | fake
+        self.dA = stage(NT)
+        self.dH = stage(NT)
+        self.dH[0] = self.X0
+        self.dU = stage(NT)
+        self.dJ = stage(NT)
+        self.dStat = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]    # mu, rstd
+        self.dStatB = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]   # mean(w), mean(w xhat)
+        self.dStatT = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]   # mean(t), mean(xhat t)
         # per-sample gamma | beta partial sums side by side, so one row reduction yields both gradients
-        self.dPGB = [None] + [torch.zeros(NT, 2 * D2_CH[k], **f) for k in range(1, 5)]
-        self.dPG = [None] + [self.dPGB[k][:, :D2_CH[k]] for k in range(1, 5)]
-        self.dPB = [None] + [self.dPGB[k][:, D2_CH[k]:] for k in range(1, 5)]
-        self.G0 = torch.zeros(max(NPl, B), 1, 64, 64, **f)   # input gradient of penalised samples / gen step
-        self.d1A = [torch.zeros(2 * B, D1_CH[i + 1], D1_LEN[i + 1], **f) for i in range(3)]
-        self.F1 = torch.zeros(2 * B, FEAT1, **f)
-        self.dP0 = torch.zeros(B, 1, 64, **f)            # d loss / d positions (generator step)
+        # (columns laid out like the [gamma | beta] stretch of the flat gradient buffer, whose slices start on multiples
+        # of 64 floats: for a stage of fewer channels there is a gap between the two, which stays zero)
+        gap = [None] + [self.D.offsets[f"twod_conv_layers.{3 * (k - 1) + 1}.bias"]
+                        - self.D.offsets[f"twod_conv_layers.{3 * (k - 1) + 1}.weight"] for k in range(1, nS + 1)]
+        self.dPGB = [None] + [torch.zeros(NT, gap[k] + d2c[k], **f) for k in range(1, nS + 1)]
+        self.dPG = [None] + [self.dPGB[k][:, :d2c[k]] for k in range(1, nS + 1)]
+        self.dPB = [None] + [self.dPGB[k][:, gap[k]:] for k in range(1, nS + 1)]
+        self.G0 = torch.zeros(max(NPl, B), 1, S, S, **f)   # input gradient of penalised samples / gen step
+        self.d1A = [torch.zeros(2 * B, D1_CH[i + 1], dm["d1l"][i + 1], **f) for i in range(3)]
+        self.F1 = torch.zeros(2 * B, self.feat1, **f)
+        self.dP0 = torch.zeros(B, 1, S, **f)             # d loss / d positions (generator step)
         self.score = torch.zeros(2 * B, **f)
         self.coef = torch.zeros(NT, **f)                 # per-slot seed / head-gradient weights
         self.coef_head = torch.zeros(NT, **f)
         self.coef_top = torch.zeros(NPl, **f)        # div: Wasserstein seed of the penalised samples
-        self.HB4 = torch.zeros(NPl, 512, 4, 4, **f)  # div: primal adjoint entering the top stage
+        self.HB4 = torch.zeros(NPl, d2c[nS], d2h[nS], d2h[nS], **f)  # div: primal adjoint entering the top stage
         self.pen = torch.zeros(1, **f)
         self.closs = torch.zeros(4, **f)                 # W, mean real, mean fake, penalty
         self.gloss = torch.zeros(1, **f)
@@ -275,28 +321,22 @@ class Engine:
         if not generator_only:
             self._init_coefs()
 
-        # ---- generator workspace ----
-        g2c = (latent, 512, 256, 128, 64, 1)
-        g2h = (1, 4, 8, 16, 32, 64)
-        self.g2c, self.g2h = g2c, g2h
+        # ---- generator workspace: index i = 1..nG is the i-th BatchNorm stage ----
+        g2c, g2h, g1c, g1l, nG = dm["g2c"], dm["g2h"], dm["g1c"], dm["g1l"], self.nG
+        self.g2c, self.g2h, self.g1c, self.g1l = g2c, g2h, g1c, g1l
+        g2 = lambda: [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, nG + 1)]
+        g1 = lambda: [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, nG + 1)]
         self.Z = torch.zeros(B, latent, **f)
-        self.gA = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]   # conv outputs
-        self.gH = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]   # after BN+LReLU
-        self.gStat = [None] + [torch.zeros(2, g2c[i], **f) for i in range(1, 5)]
-        self.gdH = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]
-        self.gdA = [None] + [torch.zeros(B, g2c[i], g2h[i], g2h[i], **f) for i in range(1, 5)]
-        self.gXs = torch.zeros(B, 1, 64, 64, **f)        # generator-step output (sites)
-        self.gXp = torch.zeros(B, 1, 64, **f)
-        self.gdX = torch.zeros(B, 1, 64, 64, **f)
-        g1c = (latent, latent // 2, latent // 4, latent // 8, latent // 16, 1)
-        g1l = (1, 4, 8, 16, 32, 64)
-        self.g1c, self.g1l = g1c, g1l
-        self.hA = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
-        self.hH = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
-        self.hStat = [None] + [torch.zeros(2, g1c[i], **f) for i in range(1, 5)]
-        self.hdH = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
-        self.hdA = [None] + [torch.zeros(B, g1c[i], g1l[i], **f) for i in range(1, 5)]
-        self.hdX = torch.zeros(B, 1, 64, **f)
+        self.gA, self.gH = g2(), g2()                    # conv outputs; after BN+LReLU
+        self.gStat = [None] + [torch.zeros(2, g2c[i], **f) for i in range(1, nG + 1)]
+        self.gdH, self.gdA = g2(), g2()
+        self.gXs = torch.zeros(B, 1, S, S, **f)          # generator-step output (sites)
+        self.gXp = torch.zeros(B, 1, S, **f)
+        self.gdX = torch.zeros(B, 1, S, S, **f)
+        self.hA, self.hH = g1(), g1()
+        self.hStat = [None] + [torch.zeros(2, g1c[i], **f) for i in range(1, nG + 1)]
+        self.hdH, self.hdA = g1(), g1()
+        self.hdX = torch.zeros(B, 1, S, **f)
 
     # ------------------------------------------------------------------------------------------
     def _init_coefs(self, wasserstein: bool = True):
@@ -332,13 +372,19 @@ class Engine:
         (the two tensors are adjacent there: sizes are multiples of the 64-float slice alignment)."""
         if getattr(self, "_gnpairs", None) is None:
             pairs = []
-            for k in range(1, 5):
+            for k in range(1, self.nS + 1):
                 n = f"twod_conv_layers.{3 * (k - 1) + 1}"
-                off, c = self.D.offsets[n + ".weight"], D2_CH[k]
-                assert self.D.offsets[n + ".bias"] == off + c
-                pairs.append(self.D.gflat[off:off + 2 * c])
+                off, c = self.D.offsets[n + ".weight"], self.d2c[k]
+                pairs.append(self.D.gflat[off:self.D.offsets[n + ".bias"] + c])
             self._gnpairs = pairs
         return self._gnpairs
+
+    def _reduce_norm_grads(self, r0, r1, r2, r3) -> None:
+        """[gamma | beta] gradients of every stage from the per-sample partial sums of rows [r0,r1) and [r2,r3)
+        (at most four stages per launch)."""
+        pairs = self._gn_grad_pairs()
+        for lo in range(0, self.nS, 4):
+            self.ops.rows_reduce_multi(self.dPGB[1 + lo:5 + lo], pairs[lo:lo + 4], r0, r1, r2, r3)
 
     def _d1d_params(self, store):
         cw = [store[f"oned_conv_layers.{3 * i}.weight"] for i in range(3)]
@@ -425,12 +471,12 @@ class Engine:
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         Z, gA, gH, gStat = bufs if bufs is not None else (self.Z, self.gA, self.gH, self.gStat)
         o.gemm_nn(Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), gA[1].view(Z.shape[0], -1))
-        for i in range(1, 5):
+        for i in range(1, self.nG + 1):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
             self._bn_fwd(n, gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
                          Gb[n + ".running_var"], gH[i], gStat[i], groups)
             w = G[f"twod_conv_layers.{3 * i}.weight"]
-            if i < 4:
+            if i < self.nG:
                 o.conv_up(gH[i], w, gA[i + 1])
             else:
                 o.conv_up(gH[i], w, out_s, self.act_id)
@@ -439,12 +485,12 @@ class Engine:
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         Z, hA, hH, hStat = bufs if bufs is not None else (self.Z, self.hA, self.hH, self.hStat)
         o.gemm_nn(Z, G["oned_conv_layers.0.weight"].view(self.latent, -1), hA[1].view(Z.shape[0], -1))
-        for i in range(1, 5):
+        for i in range(1, self.nG + 1):
             n = f"oned_conv_layers.{3 * (i - 1) + 1}"
             self._bn_fwd(n, hA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
                          Gb[n + ".running_var"], hH[i], hStat[i], groups)
             w = G[f"oned_conv_layers.{3 * i}.weight"]
-            if i < 4:
+            if i < self.nG:
                 o.convt1d_up(hH[i], w, hA[i + 1])
             else:
                 o.convt1d_up(hH[i], w, out_p, self.act_id)
@@ -458,17 +504,18 @@ class Engine:
         f = dict(dtype=torch.float32, device=dev)
         self.gen_chunks = m
         self.Zw = torch.zeros(m * B, self.latent, **f)
-        self.gAw = [None] + [torch.zeros(m * B, *self.gA[i].shape[1:], **f) for i in range(1, 5)]
-        self.gHw = [None] + [torch.zeros(m * B, *self.gH[i].shape[1:], **f) for i in range(1, 5)]
-        self.gStatw = [None] + [torch.zeros(m, 2, self.gStat[i].shape[1], **f) for i in range(1, 5)]
-        self.hAw = [None] + [torch.zeros(m * B, *self.hA[i].shape[1:], **f) for i in range(1, 5)]
-        self.hHw = [None] + [torch.zeros(m * B, *self.hH[i].shape[1:], **f) for i in range(1, 5)]
-        self.hStatw = [None] + [torch.zeros(m, 2, self.hStat[i].shape[1], **f) for i in range(1, 5)]
-        self.fake_s = torch.zeros(m * B, 1, 64, 64, **f)
-        self.fake_p = torch.zeros(m * B, 1, 64, **f)
+        R, S = range(1, self.nG + 1), self.data
+        self.gAw = [None] + [torch.zeros(m * B, *self.gA[i].shape[1:], **f) for i in R]
+        self.gHw = [None] + [torch.zeros(m * B, *self.gH[i].shape[1:], **f) for i in R]
+        self.gStatw = [None] + [torch.zeros(m, 2, self.gStat[i].shape[1], **f) for i in R]
+        self.hAw = [None] + [torch.zeros(m * B, *self.hA[i].shape[1:], **f) for i in R]
+        self.hHw = [None] + [torch.zeros(m * B, *self.hH[i].shape[1:], **f) for i in R]
+        self.hStatw = [None] + [torch.zeros(m, 2, self.hStat[i].shape[1], **f) for i in R]
+        self.fake_s = torch.zeros(m * B, 1, S, S, **f)
+        self.fake_p = torch.zeros(m * B, 1, S, **f)
         lo = (m - 1) * B
         self.Z = self.Zw[lo:]
-        for i in range(1, 5):
+        for i in R:
             self.gA[i], self.gH[i], self.gStat[i] = self.gAw[i][lo:], self.gHw[i][lo:], self.gStatw[i][m - 1]
             self.hA[i], self.hH[i], self.hStat[i] = self.hAw[i][lo:], self.hHw[i][lo:], self.hStatw[i][m - 1]
         self.gXs, self.gXp = self.fake_s[lo:], self.fake_p[lo:]
@@ -497,7 +544,7 @@ class Engine:
         o, G, dG = self.ops, self.G.p, self.G.g
         o.act_bwd(dxs, xs, self.gdX, self.act_id)
         up = self.gdX
-        for i in range(4, 0, -1):
+        for i in range(self.nG, 0, -1):
             w = G[f"twod_conv_layers.{3 * i}.weight"]
             self.wside.fork()
             with self.wside:      # the weight gradient beside the input-gradient chain
@@ -516,7 +563,7 @@ class Engine:
         o, G, dG = self.ops, self.G.p, self.G.g
         o.act_bwd(dxp, xp, self.hdX, self.act_id)
         up = self.hdX
-        for i in range(4, 0, -1):
+        for i in range(self.nG, 0, -1):
             w = G[f"oned_conv_layers.{3 * i}.weight"]
             o.convt1d_wgrad(self.hH[i], up, dG[f"oned_conv_layers.{3 * i}.weight"])
             o.convt1d_down(up, w, self.hdH[i])
@@ -531,7 +578,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def _d_forward2d(self, lo: int, hi: int) -> None:
         o = self.ops
-        for k in range(1, 5):
+        for k in range(1, self.nS + 1):
             o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi])
             gw, gb = self.dgn(k)
             o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi])
@@ -540,8 +587,8 @@ class Engine:
         """First-order backward of sum_n coef[n] * score[n] through the 2-D tower for slots [lo, hi).
         The input gradient is produced only for slots [g_lo, g_hi) (into g_out)."""
         o = self.ops
-        o.head_seed(self.D.p["out.weight"], self.coef_cur[lo:hi], self.dU[4][lo:hi])
-        for k in range(4, 0, -1):
+        o.head_seed(self.D.p["out.weight"], self.coef_cur[lo:hi], self.dU[self.nS][lo:hi])
+        for k in range(self.nS, 0, -1):
             gw, _ = self.dgn(k)
             o.gn_bwd(self.dU[k][lo:hi], self.dH[k][lo:hi], self.dA[k][lo:hi], self.dStat[k][lo:hi], gw,
                      self.dJ[k][lo:hi], self.dStatB[k][lo:hi], self.dPG[k][lo:hi], self.dPB[k][lo:hi])
@@ -560,7 +607,7 @@ class Engine:
         self._d_forward2d(0, n)
         cw, cb, gw, gb = self._d1d_params(self.D.p)
         o.d1d_fwd(self.P0[:n], cw, cb, gw, gb, [a[:n] for a in self.d1A], self.F1[:n])
-        o.head_fwd(self.dH[4][:n], self.F1[:n], self.D.p["out.weight"], self.D.p["out.bias"], score)
+        o.head_fwd(self.dH[self.nS][:n], self.F1[:n], self.D.p["out.weight"], self.D.p["out.bias"], score)
 
     def disc_backward(self, n: int, coef: torch.Tensor, dxs: Optional[torch.Tensor] = None,
                       dxp: Optional[torch.Tensor] = None, want_params: bool = True) -> None:
@@ -571,12 +618,13 @@ class Engine:
         self.coef_cur = coef
         self._d_backward1(0, n, 0, n, dxs)
         a1 = [a[:n] for a in self.d1A]
+        FEAT2 = self.feat2
         wt = Dp["out.weight"].view(-1)[FEAT2:]
         if want_params:
-            for k in range(1, 5):
+            for k in range(1, self.nS + 1):
                 o.conv_wgrad(self.dJ[k][:n], self.dH[k - 1][:n], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
-            o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), 0, n, 0, 0)
-            o.head_wgrad(self.dH[4][:n], coef, Dg["out.weight"].view(-1)[:FEAT2])
+            self._reduce_norm_grads(0, n, 0, 0)
+            o.head_wgrad(self.dH[self.nS][:n], coef, Dg["out.weight"].view(-1)[:FEAT2])
             o.head_wgrad(self.F1[:n], coef, Dg["out.weight"].view(-1)[FEAT2:])
             o.head_wgrad(self.ones2B[:n], coef, Dg["out.bias"])
             dcw, dcb, dgw, dgb = self._d1d_params(Dg)
@@ -616,6 +664,7 @@ class Engine:
         z in Z, t in tbuf (and, with run_generator=False, the fake batch in X0[B:2B] / P0[B:2B])."""
         o, B, NS, NP, NT = self.ops, self.B, self.NS, self.NP, self.NT
         Dp, Dg = self.D.p, self.D.g
+        nS, FEAT2 = self.nS, self.feat2
         self._fresh()
         cw, cb, gw, gb = self._d1d_params(Dp)
         dcw, dcb, dgw, dgb = self._d1d_params(Dg)
@@ -643,14 +692,14 @@ class Engine:
             # length; they run side by side, each one's convolutions beside the other's small kernels.  The
             # Wasserstein chain goes first on the weight-gradient stream.
             if hasattr(o, "prepare_weights"):
-                o.prepare_weights([self.dconv_w(k) for k in range(1, 5)])
+                o.prepare_weights([self.dconv_w(k) for k in range(1, nS + 1)])
             self.wside.fork()
             with self.wside:
                 self._d_forward2d(0, 2 * B)
                 self.side.wait_mark()
-                o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
+                o.head_fwd(self.dH[nS][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
                 self._d_backward1(0, 2 * B, 0, 0, None)
-                for k in (range(4, 0, -1) if self.split_wgrad else ()):
+                for k in (range(nS, 0, -1) if self.split_wgrad else ()):
                     o.conv_wgrad(self.dJ[k][:2 * B], self.dH[k - 1][:2 * B], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
             self._d_forward2d(2 * B, NS)
@@ -661,7 +710,7 @@ class Engine:
             # primal forward
             self._d_forward2d(0, NS)
             self.side.wait_mark()
-            o.head_fwd(self.dH[4][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
+            o.head_fwd(self.dH[nS][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
             # first-order backward (+ input gradient of the penalised samples)
             self._d_backward1(0, NS, NS - NP, NS, self.G0[:NP])
         # penalty value and v = d penalty / d g, written as the tangent input
@@ -671,7 +720,7 @@ class Engine:
             o.div_penalty(self.G0[:NP], B, self.X0[NS:NT], self.pen)
         # tangent forward of v through the 2-D tower (primal state = the penalised samples' slots)
         pl, ph = NS - NP, NS
-        for k in range(1, 5):
+        for k in range(1, nS + 1):
             o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT])
             gw_k, _ = self.dgn(k)
             o.gn_jvp(self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph], self.dStat[k][pl:ph], gw_k,
@@ -681,7 +730,7 @@ class Engine:
         if self.loss == "div":
             o.head_seed(Dp["out.weight"], self.coef_top, self.HB4)
             hbar = self.HB4
-        for k in range(4, 0, -1):
+        for k in range(nS, 0, -1):
             gw_k, _ = self.dgn(k)
             o.gn_bwd2(hbar, self.dU[k][pl:ph], self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph],
                       self.dStat[k][pl:ph], self.dStatB[k][pl:ph], self.dStatT[k][NS:NT], gw_k,
@@ -705,8 +754,8 @@ class Engine:
             o.release_weights()
         o.critic_loss(self.score, B, self.pen, self.closs)
         r = (0, 2 * B, NS, NT) if self.loss == "gp" else (NS, NT, 0, 0)
-        o.rows_reduce_multi(self.dPGB[1:], self._gn_grad_pairs(), *r)
-        o.head_wgrad(self.dH[4], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
+        self._reduce_norm_grads(*r)
+        o.head_wgrad(self.dH[nS], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
         self.side.join()
 
     def critic_step(self, real_s, real_p, z, t=None) -> None:
@@ -727,6 +776,7 @@ class Engine:
         activations in the generator workspace, from gen_forward_resident(self.gXs, self.gXp))."""
         o, B = self.ops, self.B
         Dp = self.D.p
+        nS, FEAT2 = self.nS, self.feat2
         self._fresh()
         cw, cb, gw, gb = self._d1d_params(Dp)
         a1 = [a[:B] for a in self.d1A]
@@ -747,7 +797,7 @@ class Engine:
         o.affine(self.gXs, 1.0, 0.0, self.X0[:B])                          # copy
         self._d_forward2d(0, B)
         self.side.wait_mark()
-        o.head_fwd(self.dH[4][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])
+        o.head_fwd(self.dH[nS][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])
         o.neg_mean(self.score[:B], self.gloss)
         self.coef_cur = self.coef_gen
         self._d_backward1(0, B, 0, B, self.G0[:B])

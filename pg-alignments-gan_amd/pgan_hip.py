@@ -67,6 +67,8 @@ _SIGS = {
     "pgan_take_batch": [P, P, P, P, P, I, I, I, I, P],
     "pgan_d1d_fwd": [P, P, P, P, P, P, I, P],
     "pgan_d1d_bwd": [P, P, P, P, P, P, P, P, I, P, P, I, P],
+    "pgan_d1d_fwd_len": [P, P, P, P, P, P, I, I, P],
+    "pgan_d1d_bwd_len": [P, P, P, P, P, P, P, P, I, P, P, I, I, P],
     "pgan_ct1d_up": [P, P, P, I, I, I, I, I, P],
     "pgan_ct1d_down": [P, P, P, I, I, I, I, P],
     "pgan_ct1d_wgrad": [P, P, P, I, I, I, I, P],
@@ -76,7 +78,7 @@ _SIGS = {
     "pgan_pack_sites": [P, P, L, P],
     "pgan_gn_fwd_static": [P, P, P, P, P, I, I, I, P],
     "pgan_fakebuf_step": [P, P, I, P, P, P, P, P, P, I, I, I, P, P, P],
-    "pgan_sample_genotypes": [P, P, L, I, P, I, P],
+    "pgan_sample_genotypes": [P, P, L, I, I, P, I, P],
     "pgan_parse_ms": [ctypes.c_char_p, L, I, I, I, P, P],
     "pgan_step_graph_begin": [P],
     "pgan_step_graph_end": [P, ctypes.POINTER(ctypes.c_void_p)],
@@ -543,8 +545,8 @@ class HipOps:
                "pgan_fakebuf_step")
 
     def sample_genotypes(self, p, out, rng, require_variation=True):
-        assert p.dim() == 4 and p.shape[1] == 1 and p.shape[2] == 64 and tuple(out.shape) == tuple(p.shape)
-        _check(_lib.pgan_sample_genotypes(_ptr(p), _ptr(out), p.shape[0], p.shape[3], rng.data_ptr(),
+        assert p.dim() == 4 and p.shape[1] == 1 and tuple(out.shape) == tuple(p.shape)
+        _check(_lib.pgan_sample_genotypes(_ptr(p), _ptr(out), p.shape[0], p.shape[2], p.shape[3], rng.data_ptr(),
                                           int(require_variation), _stream()), "pgan_sample_genotypes")
 
     # ---------------- discriminator 1-D tower ----------------
@@ -561,8 +563,8 @@ class HipOps:
     def d1d_fwd(self, xp, cw, cb, gw, gb, a_save, feat):
         N = xp.shape[0]
         arr = self._param_array(cw, cb, gw, gb)
-        _check(_lib.pgan_d1d_fwd(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(feat), N,
-                                 _stream()), "pgan_d1d_fwd")
+        _check(_lib.pgan_d1d_fwd_len(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(feat), N,
+                                     xp.shape[-1], _stream()), "pgan_d1d_fwd_len")
 
     def d1d_bwd(self, xp, cw, cb, gw, gb, a_save, coef, w_tail, d_cw, d_cb, d_gw, d_gb, dxp):
         N = xp.shape[0]
@@ -587,8 +589,9 @@ class HipOps:
             ld = span
             offs = (c_int * 12)(*rel)
             part = self.d1_part
-        _check(_lib.pgan_d1d_bwd(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(coef),
-                                 _ptr(w_tail), _ptr(part), ld, offs, _ptr(dxp), N, _stream()), "pgan_d1d_bwd")
+        _check(_lib.pgan_d1d_bwd_len(_ptr(xp), arr, _ptr(a_save[0]), _ptr(a_save[1]), _ptr(a_save[2]), _ptr(coef),
+                                     _ptr(w_tail), _ptr(part), ld, offs, _ptr(dxp), N, xp.shape[-1], _stream()),
+               "pgan_d1d_bwd_len")
         if d_cw is not None:
             if flat:
                 first = min(dsts, key=lambda t: t.data_ptr())

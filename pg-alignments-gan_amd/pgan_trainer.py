@@ -26,9 +26,11 @@ class FusedTrainer:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  critic_iter: int = 5, seed: int = 1234, lr_d: float = 5e-5, lr_g: float = 5e-5,
                  latent: int = 128, process_group=None, rank: int = 0, world: int = 1, sync_bn: Optional[bool] = None,
-                 batched_generator: bool = True):
+                 batched_generator: bool = True, data: int = 64):
+        """data: side of the square alignments, 64 (the reference's networks) or 128 (the scaled networks)."""
         self.ops, self.dev, self.critic_iter = ops, torch.device(device), int(critic_iter)
-        self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g)
+        self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g,
+                          data=data)
         self.eng.use_device_step_counters()
         # the generator forwards of an iteration after the first (critic steps 2.., the generator step's own) share
         # their weights and run as ONE pass over (critic_iter) x batch samples beside the first critic step
@@ -77,10 +79,12 @@ class FusedTrainer:
         size) or over each rank's own samples (False: no collectives inside the generator)."""
         self.pg, self.dist_active = process_group, True
         self.tape = None
-        # A backend that stages device tensors through the host (gloo) runs each collective on streams of its own and
-        # completes it from a host thread: its copies then wait, from other hardware queues, on the engine's four busy
-        # compute streams, and a step was seen to stall on the GPU that way.  Such a backend gets an idle device at
-        # every collective (its result is host-synchronous anyway); RCCL enqueues on the calling stream and needs none.
+        # Only RCCL reduces device memory in place, enqueued on the calling stream.  With any other backend (gloo: a
+        # rehearsal of the data-parallel path on a box with one GPU) the trainer stages each collective through host
+        # memory itself -- drain the device, copy out, reduce on the host, copy back -- instead of handing device
+        # tensors to the backend: gloo's own device staging (copies on streams of its own, completed from a helper
+        # thread) was seen to stall two ranks that share one GPU, both between the engine's four busy streams and at
+        # the end of a long-lived test process.
         import torch.distributed as dist
         self._drain = self.dev.type == "cuda" and dist.is_initialized() and dist.get_backend(process_group) != "nccl"
         # collectives run on "the current stream": a launch tape replays them under the stream they were issued on
@@ -131,8 +135,9 @@ class FusedTrainer:
         self.pool_s.copy_(self.pool_s[perm])
         self.pool_p.copy_(self.pool_p[perm])
         if rows:
-            order = torch.rand(n, 64, device=self.dev).argsort(dim=1)
-            idx = order.view(n, 1, 64, 1).expand(n, 1, 64, 64)
+            S = self.pool_s.shape[-1]
+            order = torch.rand(n, S, device=self.dev).argsort(dim=1)
+            idx = order.view(n, 1, S, 1).expand(n, 1, S, S)
             self.pool_s.copy_(torch.gather(self.pool_s, 2, idx))
         self.cursor.zero_()
 
@@ -144,8 +149,9 @@ class FusedTrainer:
         logical indices (0 = oldest): a test drives it beside the reference's host deque."""
         B = self.eng.B
         assert size >= B
-        self.buf_s = torch.zeros(size, 1, 64, 64, device=self.dev)
-        self.buf_p = torch.zeros(size, 1, 64, device=self.dev)
+        S = self.eng.data
+        self.buf_s = torch.zeros(size, 1, S, S, device=self.dev)
+        self.buf_p = torch.zeros(size, 1, S, device=self.dev)
         self.buf_state = torch.zeros(4, dtype=torch.int32, device=self.dev)     # head, count, error flag, spare
         self.buf_slots = torch.zeros(B, dtype=torch.int32, device=self.dev)
         seed = int(self.rng_z[0]) + 2
@@ -181,19 +187,24 @@ class FusedTrainer:
         if self.dist_active:
             pgan_tape.call(self._allreduce, flat, on_current_stream=True)
 
-    def _bn_allreduce(self, part: torch.Tensor) -> None:
+    def _sum_over_ranks(self, t: torch.Tensor, async_op: bool = False):
+        """all-reduce(sum) of a device tensor in place: on the device over RCCL, through host memory otherwise."""
         import torch.distributed as dist
         if self._drain:
             torch.cuda.synchronize()
-        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.pg)
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(host)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+
+    def _bn_allreduce(self, part: torch.Tensor) -> None:
+        self._sum_over_ranks(part)
 
     def _early_reduce(self, name: str, store=None, names=None) -> None:
         store = self.eng.D if store is None else store
         if name in (self.early_names if names is None else names):
-            import torch.distributed as dist
-            if self._drain:
-                torch.cuda.synchronize()
-            work = dist.all_reduce(store.g[name], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            work = self._sum_over_ranks(store.g[name], async_op=True)
             self._early.append((store, name, work))
 
     def _early_reduce_g(self, name: str) -> None:
@@ -204,9 +215,6 @@ class FusedTrainer:
         reduction was already started by _early_reduce are only waited for."""
         if not self.dist_active:
             return
-        import torch.distributed as dist
-        if self._drain:
-            torch.cuda.synchronize()
         store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else self.eng.G
         mine = [(n, w) for st, n, w in self._early if st is store]
         if flat.data_ptr() == store.gflat.data_ptr() and mine:
@@ -214,13 +222,14 @@ class FusedTrainer:
             lo = 0
             for a, b in done + [(flat.numel(), flat.numel())]:
                 if a > lo:
-                    dist.all_reduce(flat[lo:a], op=dist.ReduceOp.SUM, group=self.pg)
+                    self._sum_over_ranks(flat[lo:a])
                 lo = b
             for _, work in mine:
-                work.wait()
+                if work is not None:
+                    work.wait()
             self._early = [e for e in self._early if e[0] is not store]
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            self._sum_over_ranks(flat)
         if self.world > 1:
             self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
@@ -278,8 +287,9 @@ class FusedTrainer:
         e, o = self.eng, self.ops
         B, gs, n = e.B, e.gside, self.critic_iter
         if getattr(self, "fa_s", None) is None or len(self.fa_s) != n:
-            self.fa_s = [torch.zeros(B, 1, 64, 64, device=self.dev) for _ in range(n)]
-            self.fa_p = [torch.zeros(B, 1, 64, device=self.dev) for _ in range(n)]
+            S = e.data
+            self.fa_s = [torch.zeros(B, 1, S, S, device=self.dev) for _ in range(n)]
+            self.fa_p = [torch.zeros(B, 1, S, device=self.dev) for _ in range(n)]
             self.fa_done = [torch.cuda.Event() if self.dev.type == "cuda" else None for _ in range(n)]
         gs.fork()
         with gs:
@@ -313,8 +323,9 @@ class FusedTrainer:
         e, o = self.eng, self.ops
         B, gs = e.B, e.gside
         if getattr(self, "fk_s", None) is None:
-            self.fk_s = [torch.zeros(B, 1, 64, 64, device=self.dev) for _ in range(2)]
-            self.fk_p = [torch.zeros(B, 1, 64, device=self.dev) for _ in range(2)]
+            S = e.data
+            self.fk_s = [torch.zeros(B, 1, S, S, device=self.dev) for _ in range(2)]
+            self.fk_p = [torch.zeros(B, 1, S, device=self.dev) for _ in range(2)]
         gs.fork()
         with gs:
             o.philox(e.Z, self.rng_z, True)

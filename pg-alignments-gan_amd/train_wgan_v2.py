@@ -40,7 +40,8 @@ class DataGeneratorDisk(object):
     `<n>_pos.csv` (64 floats, one per line) pairs; `num_in` of them are drawn with random.sample
     (ValueError if the directory holds fewer), shuffled every epoch and served in batches."""
 
-    def __init__(self, idir, num_in=10000, batch_size=8):
+    def __init__(self, idir, num_in=10000, batch_size=8, data_size=64):
+        self.data_size = int(data_size)      # individuals = sites per alignment (64; 128 for the scaled networks)
         pos = {os.path.basename(p)[:-len("_pos.csv")]: p for p in glob.glob(os.path.join(idir, "*_pos.csv"))}
         sites = {os.path.basename(p)[:-len("_sites.csv")]: p for p in glob.glob(os.path.join(idir, "*_sites.csv"))}
         keys = sorted(set(pos) & set(sites))
@@ -71,11 +72,12 @@ class DataGeneratorDisk(object):
                 np.random.shuffle(s)
             sites.append(s)
             pos.append(p)
-        sites = np.array(sites, dtype=np.float32).reshape(len(sel), 64, 64) if sel else np.zeros((0, 64, 64), np.float32)
+        S = self.data_size
+        sites = np.array(sites, dtype=np.float32).reshape(len(sel), S, S) if sel else np.zeros((0, S, S), np.float32)
         if label_smooth:
             ey = np.random.uniform(0.0, 0.05, sites.shape)
             sites = sites * (1 - ey) + 0.05 * ey
-        pos = np.array(pos, dtype=np.float32).reshape(len(sel), 64) if sel else np.zeros((0, 64), np.float32)
+        pos = np.array(pos, dtype=np.float32).reshape(len(sel), S) if sel else np.zeros((0, S), np.float32)
         return torch.FloatTensor(sites[:, None]), torch.FloatTensor(pos[:, None])
 
     def load_packed(self, threads=8):
@@ -89,14 +91,16 @@ class DataGeneratorDisk(object):
         """Every selected alignment, in index order: (num_in,1,64,64), (num_in,1,64) fp32.  Native parser when the
         sites are 0 / 1 (the values equal np.loadtxt's bit for bit), np.loadtxt otherwise."""
         import alignment_slab
-        try:
-            bits, pos = self.load_packed()
-            return (torch.from_numpy(alignment_slab.unpack_numpy(bits)[:, None]),
-                    torch.from_numpy(pos[:, None].copy()))
-        except alignment_slab.NotPackable:
-            pass
-        s = np.empty((len(self.indices), 1, 64, 64), np.float32)
-        p = np.empty((len(self.indices), 1, 64), np.float32)
+        S = self.data_size
+        if S == 64:          # the packed format holds 64 x 64 alignments
+            try:
+                bits, pos = self.load_packed()
+                return (torch.from_numpy(alignment_slab.unpack_numpy(bits)[:, None]),
+                        torch.from_numpy(pos[:, None].copy()))
+            except alignment_slab.NotPackable:
+                pass
+        s = np.empty((len(self.indices), 1, S, S), np.float32)
+        p = np.empty((len(self.indices), 1, S), np.float32)
         for i, u in enumerate(self.indices):
             s[i, 0], p[i, 0] = self.read_pair(self.sites[u], self.positions[u])
         return torch.from_numpy(s), torch.from_numpy(p)
@@ -286,6 +290,9 @@ def parse_args(argv=None):
     p.add_argument("--slab", default="None",
                    help="packed copy of the selected input (bits + positions): read if the file exists, else written "
                         "after parsing --idir; later runs start without touching the CSV files")
+    p.add_argument("--data_size", default="64",
+                   help="individuals = sites per alignment: 64 (the reference's networks) or 128 (scaled networks with one "
+                        "more stride-2 stage; no counterpart in the reference)")
     p.add_argument("--local_bn", action="store_true",
                    help="several GPUs: BatchNorm statistics of each GPU's own samples instead of the global batch")
     args = p.parse_args(argv)
@@ -298,6 +305,26 @@ def parse_args(argv=None):
                 path = os.path.join(args.odir, entry)
                 shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
     return args
+
+
+def default_init(store):
+    """PyTorch's default initialisation of the layer types in `store` (conv / linear weights and biases uniform in
+    +-1/sqrt(fan_in), norm scales 1 and shifts 0), for networks that have no nn.Module front-end here."""
+    params = {}
+    fans = {}
+    for k, v in store.p.items():
+        if v.dim() > 1:
+            fan = v[0].numel()
+            fans[k[:-len(".weight")]] = fan
+            params[k] = (torch.rand(v.shape) * 2 - 1) / fan ** 0.5
+    for k, v in store.p.items():
+        if v.dim() == 1:
+            base = k.rsplit(".", 1)[0]
+            if k.endswith(".bias") and base in fans:          # bias of a convolution / the linear head
+                params[k] = (torch.rand(v.shape) * 2 - 1) / fans[base] ** 0.5
+            else:
+                params[k] = torch.ones(v.shape) if k.endswith(".weight") else torch.zeros(v.shape)
+    store.load(params)
 
 
 def state_dicts(trainer):
@@ -332,11 +359,11 @@ def plotting_forward(trainer, normalize, n=1000):
     ev = getattr(trainer, "_eval_engine", None)
     if ev is None or ev.B != n:
         ev = Engine(trainer.ops, n, trainer.dev, loss=eng.loss, act=eng.act, latent=eng.latent,
-                    g_store=eng.G, g_buffers=eng.Gbuf, d_store=eng.D, generator_only=True)
+                    g_store=eng.G, g_buffers=eng.Gbuf, d_store=eng.D, generator_only=True, data=eng.data)
         trainer._eval_engine = ev
     z = torch.randn(n, eng.latent, device=trainer.dev)
-    fs = torch.empty(n, 1, 64, 64, device=trainer.dev)
-    fp = torch.empty(n, 1, 64, device=trainer.dev)
+    fs = torch.empty(n, 1, eng.data, eng.data, device=trainer.dev)
+    fp = torch.empty(n, 1, eng.data, device=trainer.dev)
     ev.gen_forward(z, fs, fp)
     eng.g_batches_tracked += 1
     if normalize:
@@ -356,7 +383,7 @@ def evaluate_2dswd(trainer, real_sites, normalize, n=500, seed=None, generated=N
     pick = np.random.choice(range(real_sites.shape[0]), n, replace=False)
     real = real_sites[pick]
     real = real.cpu().numpy() if hasattr(real, "cpu") else np.asarray(real)
-    return plot_sfs_pca(geno, 0, real, 64, seed=seed)
+    return plot_sfs_pca(geno, 0, real, geno.shape[2], seed=seed)
 
 
 def main(argv=None):
@@ -369,6 +396,9 @@ def main(argv=None):
     latent, batch = int(args.latent_size), int(args.batch_size)
     epochs, save_freq, critic_iter = int(args.epochs), int(args.save_freq), int(args.critic_iter)
     lam, num_in = int(args.gp_lambda), int(args.num_in)
+    data_size = int(args.data_size)
+    if data_size not in (64, 128):
+        raise SystemExit("--data_size must be 64 or 128")
     act = "sigmoid" if args.gen == "sigGen" else "tanh"
     normalize = args.normalize or args.gen == "tanNorm"
     if args.plot:
@@ -387,7 +417,10 @@ def main(argv=None):
         random.seed(1234)             # the ranks pick the same --num_in files
     import alignment_slab
     bits = None
-    if args.slab != "None" and os.path.exists(args.slab):
+    if data_size != 64:           # 128 x 128: CSV files through np.loadtxt; the packed slab format is for 64 x 64
+        data = DataGeneratorDisk(args.idir, num_in=num_in, batch_size=batch, data_size=data_size)
+        sites, pos = data.load_all()
+    elif args.slab != "None" and os.path.exists(args.slab):
         bits, pos64 = alignment_slab.read_slab(args.slab)
         if bits.shape[0] < num_in:
             raise ValueError(f"{args.slab} holds {bits.shape[0]} alignments, --num_in asks for {num_in}")
@@ -415,20 +448,30 @@ def main(argv=None):
         sites = sites * (1 - ey) + hi * ey
     trainer = FusedTrainer(HipOps(dev), batch, dev, loss=args.loss, act=act, lam=lam, critic_iter=critic_iter,
                            seed=random.randrange(1 << 30), lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
-                           latent=latent, rank=rank, world=world, sync_bn=(not args.local_bn) if world > 1 else None)
+                           latent=latent, rank=rank, world=world, sync_bn=(not args.local_bn) if world > 1 else None,
+                           data=data_size)
     if world > 1:      # after the trainer, whose streams then hold the hardware queues ahead of the collective library's
         import torch.distributed as dist
         backend = os.environ.get("PGAN_DIST_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    import layers   # default PyTorch initialisation of the reference's layer types
-    g0 = (layers.DC_Generator_Leaky_Sig if act == "sigmoid" else layers.DC_Generator_Leaky_Tan)(64, latent, 0.1, 1, 4)
-    d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
-    trainer.eng.G.load({k: v for k, v in g0.state_dict().items() if k in trainer.eng.G.p})
-    trainer.eng.D.load(d0.state_dict())
+    if data_size == 64:
+        import layers   # default PyTorch initialisation of the reference's layer types
+        g0 = (layers.DC_Generator_Leaky_Sig if act == "sigmoid" else layers.DC_Generator_Leaky_Tan)(64, latent, 0.1, 1, 4)
+        d0 = layers.DC_Discriminator(64, 0.1, 1, 4)
+        trainer.eng.G.load({k: v for k, v in g0.state_dict().items() if k in trainer.eng.G.p})
+        trainer.eng.D.load(d0.state_dict())
+    else:
+        default_init(trainer.eng.G)
+        default_init(trainer.eng.D)
     if world > 1:                      # rank 0's initial weights everywhere; disjoint shares of the input
         import torch.distributed as dist
         for flat in (trainer.eng.G.flat, trainer.eng.D.flat):
-            dist.broadcast(flat, src=0)
+            if dist.get_backend() == "nccl":
+                dist.broadcast(flat, src=0)
+            else:                          # other backends move host memory (see FusedTrainer.attach_process_group)
+                host = flat.cpu()
+                dist.broadcast(host, src=0)
+                flat.copy_(host)
     trainer.weights_changed()
     if bits is not None:
         trainer.set_pool_packed(bits[rank::world], pos64[rank::world], normalize=normalize)

@@ -16,10 +16,10 @@ def z_draw(seed, b):
     return torch.from_numpy(rng.standard_normal((b, orc.LATENT, 1, 1)).astype(np.float32))
 
 
-def make_engine(B, loss, act, seed):
-    eng = Engine(TorchOps(), B, torch.device("cpu"), loss=loss, act=act)
-    gp_ = orc.make_params(orc.gen_param_shapes(), seed)
-    dp = orc.make_params(orc.disc_param_shapes(), seed + 1)
+def make_engine(B, loss, act, seed, data=64):
+    eng = Engine(TorchOps(), B, torch.device("cpu"), loss=loss, act=act, data=data)
+    gp_ = orc.make_params(orc.gen_param_shapes(data=data), seed)
+    dp = orc.make_params(orc.disc_param_shapes(data), seed + 1)
     eng.G.load(gp_)
     eng.D.load(dp)
     return eng, gp_, dp
@@ -73,3 +73,31 @@ def test_train_iteration_matches_oracle():
     for k, v in gp_.items():
         assert rel_err(eng.G.p[k], v) < 1e-5, k
     assert eng.g_batches_tracked == 3
+
+
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_scaled_network_128_matches_autograd(loss):
+    """The 128 x 128 networks (one more stride-2 stage; build-defined, the reference has none): critic and generator
+    gradients of the engine's host logic against the oracle's autograd on the same layer tables."""
+    B, seed, S = 2, 41, 128
+    eng, gp_, dp = make_engine(B, loss, "tanh", seed, data=S)
+    assert eng.nS == 5 and eng.nG == 5 and eng.feat1 == 64 * 119
+    rs, rp = orc.synthetic_alignments(B, seed + 3, size=S)
+    rs, rp = (rs - 0.5) / 0.5, (rp - 0.5) / 0.5
+    z = z_draw(seed + 2, B)
+    t = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 4)).random((B, 1, 1, 1))).float()
+    gbuf = orc.make_gen_buffers(data=S)
+    w, grads = orc.critic_grads(dp, gp_, gbuf, rs, rp, z, loss, 10.0, t, "tanh")
+    eng.critic_grads(rs, rp, z, t)
+    assert abs(float(eng.closs[0]) - float(w)) <= 1e-5 * max(1.0, abs(float(w)))
+    for k, g in grads.items():
+        e = rel_err(eng.D.g[k], g) if float(g.norm()) > 0 else float(eng.D.g[k].abs().max())
+        assert e < 2e-5, (k, e)
+    for k, v in gbuf.items():
+        if "running" in k:
+            assert rel_err(eng.Gbuf.p[k], v) < 1e-6, k
+    gl, ggrads = orc.generator_grads(dp, gp_, None, z, "tanh")
+    eng.generator_grads(z)
+    assert abs(float(eng.gloss) - float(gl)) <= 1e-5 * max(1.0, abs(float(gl)))
+    for k, g in ggrads.items():
+        assert rel_err(eng.G.g[k], g) < 2e-5, k

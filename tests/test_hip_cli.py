@@ -10,8 +10,8 @@ import dcwgan_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _write_sims(tmp, n):
-    rs, rp = orc.synthetic_alignments(n, 5)
+def _write_sims(tmp, n, size=64):
+    rs, rp = orc.synthetic_alignments(n, 5, size=size)
     for i in range(n):
         np.savetxt(os.path.join(tmp, f"{i}_sites.csv"), rs[i, 0].numpy().astype(int), fmt="%d", delimiter=",")
         np.savetxt(os.path.join(tmp, f"{i}_pos.csv"), rp[i, 0].numpy(), fmt="%.6f")
@@ -81,3 +81,23 @@ def test_train_cli_slab_cache(tmp_path):
     tw.main(argv)
     g = torch.load(odir / "generator_model_0001.pt", weights_only=True)
     assert all(bool(torch.isfinite(v.float()).all()) for v in g.values())
+
+
+def test_train_cli_scaled_128(tmp_path):
+    """--data_size 128: the scaled networks (no counterpart in the reference) from 128 x 128 CSV pairs to checkpoints
+    with one more stage per tower; the plotting forward and its genotyping run at that size too."""
+    import train_wgan_v2 as tw
+    idir, odir = tmp_path / "sims", tmp_path / "out"
+    idir.mkdir()
+    _write_sims(str(idir), 24, size=128)
+    tw.main(["--idir", str(idir), "--odir", str(odir), "--use_cuda", "--num_in", "24", "--batch_size", "4",
+             "--epochs", "1", "--save_freq", "1", "--critic_iter", "2", "--data_size", "128", "--plot"])
+    g = torch.load(odir / "generator_model_0001.pt", weights_only=True)
+    d = torch.load(odir / "discriminator_model_0001.pt", weights_only=True)
+    want_g = dict(orc.gen_param_shapes(data=128))
+    want_g.update(orc.gen_buffer_shapes(data=128))
+    assert {k: tuple(v.shape) for k, v in g.items()} == want_g
+    assert {k: tuple(v.shape) for k, v in d.items()} == orc.disc_param_shapes(128)
+    assert all(bool(torch.isfinite(v.float()).all()) for v in list(g.values()) + list(d.values()))
+    w = float((odir / "w_dist_pca.txt").read_text().split()[1])
+    assert np.isfinite(w) and w > 0

@@ -352,5 +352,13 @@ def test_sample_genotypes_on_the_device(hip):
     assert bool((out.sum(dim=2) <= 63).all())
     free = tw.sample_genotypes_bernoulli(q, require_variation=False)
     assert float((free.sum(dim=2) == 0).float().mean()) > 0.9
+    # 128 individuals (the scaled networks' alignments)
+    p128 = torch.rand(50, 1, 128, 128, generator=g).to(DEV)
+    o128 = tw.sample_genotypes_bernoulli(p128)
+    cs = o128.sum(dim=2)
+    assert bool(((o128 == 0) | (o128 == 1)).all()) and bool(((cs > 0) & (cs < 128)).all())
+    assert abs(float(o128.mean()) - float(p128.mean())) < 5 * (0.25 / p128.numel()) ** 0.5 + 1e-4
+    lo = torch.full((50, 1, 128, 128), 1e-5, device=DEV)
+    assert bool((tw.sample_genotypes_bernoulli(lo).sum(dim=2) >= 1).all())
     # two calls draw different numbers (the state advances)
     assert not torch.equal(tw.sample_genotypes_bernoulli(p), tw.sample_genotypes_bernoulli(p))

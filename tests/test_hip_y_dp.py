@@ -69,7 +69,7 @@ def _worker(rank, world, port, loss, out_dir, backend="gloo"):
     # rank r holds the global batch's rows [r B/2, (r+1) B/2); generator_grads sees them flipped within the rank
     out = _run(tr, rs, rp, t, z, slice(rank * B // world, (rank + 1) * B // world), dev)
     for k in ("closs", "gloss"):
-        v = out[k].to(dev)
+        v = out[k].to(dev) if backend == "nccl" else out[k].clone()
         dist.all_reduce(v)
         out[k] = (v / world).cpu()
     torch.cuda.synchronize()
