@@ -36,10 +36,27 @@ sys.path.insert(0, os.path.join(ROOT, "pg-alignments-gan_amd"))
 import numpy as np
 import torch
 
-F_D = 204_593_664          # discriminator forward FLOP / sample
-F_G = 205_703_168          # generator forward FLOP / sample
-FLOP_PER_ALIGNMENT = {"gp": (5 * (F_G + 12 * F_D) + 3 * F_G + 2 * F_D) / 5.0}
-FLOP_PER_ALIGNMENT["div"] = FLOP_PER_ALIGNMENT["gp"]
+def forward_flops(data=64, latent=128):
+    """(discriminator, generator) forward FLOP per sample, 2 per multiply-add, convolutions and linear layers only
+    (data = 64: 204,593,664 and 205,703,168, the reference networks' counts)."""
+    from pgan_engine import net_dims
+    dm = net_dims(data, latent)
+    d = sum(dm["d2c"][k] * dm["d2c"][k - 1] * 16 * dm["d2h"][k] ** 2 for k in range(1, len(dm["d2c"])))
+    d += sum(dm["d1c"][k] * dm["d1c"][k - 1] * 4 * dm["d1l"][k] for k in range(1, 4)) + dm["feat2"] + dm["feat1"]
+    g = dm["g2c"][0] * dm["g2c"][1] * 16 + sum(dm["g2c"][k] * dm["g2c"][k + 1] * 16 * dm["g2h"][k] ** 2
+                                               for k in range(1, len(dm["g2c"]) - 1))
+    g += dm["g1c"][0] * dm["g1c"][1] * 4 + sum(dm["g1c"][k] * dm["g1c"][k + 1] * 4 * dm["g1l"][k]
+                                               for k in range(1, len(dm["g1c"]) - 1))
+    return 2 * d, 2 * g
+
+
+def flop_per_alignment(data=64, critic_iter=5):
+    """Algorithmic FLOP of one iteration per real alignment: critic step F_G + 12 F_D per alignment (gp and div alike),
+    generator step 3 F_G + 2 F_D per latent sample, one generator step per critic_iter critic steps."""
+    f_d, f_g = forward_flops(data)
+    return (critic_iter * (f_g + 12 * f_d) + 3 * f_g + 2 * f_d) / critic_iter
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense
 PEAK_HBM_GBS = 8000.0
@@ -48,10 +65,9 @@ PEAK_HBM_GBS = 8000.0
 SUSTAINED_RANDOM_TFLOPS = {"fp32": 92.0, "bf16": 1770.0}
 
 
-def synthetic_pool(n, seed):
+def synthetic_pool(n, seed, size=64):
     """ms-style synthetic alignments: every column polymorphic, derived-allele count ~ 1/i."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    size = 64
     w = 1.0 / np.arange(1, size)
     w /= w.sum()
     counts = rng.choice(np.arange(1, size), size=(n, size), p=w)
@@ -163,7 +179,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(loss, act, batch, critic_iter, iters=3):
+def cpu_baseline(loss, act, batch, critic_iter, iters=3, data=64, one_thread_batch=None):
     """The reference's step on the host cores: the CPU oracle with the reference's wasted work included (gp: fakes
     left attached, so every critic backward also runs through the generator; the generator step's backward also
     computes the discriminator's weight gradients), on all cores of this process and on one thread (the reference's
@@ -172,15 +188,16 @@ def cpu_baseline(loss, act, batch, critic_iter, iters=3):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dcwgan_oracle as orc
     torch.manual_seed(0)
-    rs, rp = orc.synthetic_alignments(batch * critic_iter, 20263)
+    rs, rp = orc.synthetic_alignments(batch * critic_iter, 20263, size=data)
     if act == "tanh":
         rs, rp = (rs - 0.5) / 0.5, (rp - 0.5) / 0.5
-    batches = [(rs[i * batch:(i + 1) * batch], rp[i * batch:(i + 1) * batch]) for i in range(critic_iter)]
+    full_batch = batch
 
-    def run(n, reference_cost):
-        gp_ = orc.make_params(orc.gen_param_shapes(), 20261)
-        dp = orc.make_params(orc.disc_param_shapes(), 20262)
-        gbuf = orc.make_gen_buffers()
+    def run(n, reference_cost, batch=full_batch):
+        batches = [(rs[i * batch:(i + 1) * batch], rp[i * batch:(i + 1) * batch]) for i in range(critic_iter)]
+        gp_ = orc.make_params(orc.gen_param_shapes(data=data), 20261)
+        dp = orc.make_params(orc.disc_param_shapes(data), 20262)
+        gbuf = orc.make_gen_buffers(data=data)
         d_opt, g_opt = orc.AdamState(dp), orc.AdamState(gp_)
 
         def one():
@@ -198,14 +215,16 @@ def cpu_baseline(loss, act, batch, critic_iter, iters=3):
     cores = torch.get_num_threads()
     per_it = run(iters, True)
     lean = run(iters, False)
+    b1 = one_thread_batch or batch
     torch.set_num_threads(1)
     try:
-        one_thread = run(1, True)
+        one_thread = run(1, True, b1)
     finally:
         torch.set_num_threads(cores)
-    rate = lambda sec: round(critic_iter * batch / sec, 2)
+    rate = lambda sec, b=batch: round(critic_iter * b / sec, 2)
     return dict(value=rate(per_it), unit="alignments/sec", cores=cores, kind="port", cpu_model=_cpu_model(),
-                one_thread=dict(value=rate(one_thread), cores=1, sample=f"1 full iteration, {one_thread:.2f} s"),
+                one_thread=dict(value=rate(one_thread, b1), cores=1,
+                                sample=f"1 full iteration at batch {b1}, {one_thread:.2f} s"),
                 without_wasted_backward=dict(value=rate(lean), cores=cores, sample=f"{iters} full iterations, {lean:.2f} s each"),
                 sample=f"{iters} full iterations (5 critic + 1 generator step, batch {batch}, {loss} loss, {act} generator) "
                        f"after 1 warm-up, stock-PyTorch CPU oracle doing the reference's work (fakes attached in gp critic "
@@ -220,6 +239,9 @@ CONFIGS = {
             name="configs[2]: DCWGAN-GP tanNorm + --normalize, 64x64, global batch 512 data-parallel"),
     3: dict(loss="div", act="sigmoid", batch=32, global_batch=256, buffer=20, permute=True,
             name="configs[3]: DCWGAN-GP div loss + --use_buffer + --permute, 64x64, global batch 256"),
+    4: dict(loss="gp", act="sigmoid", batch=128, global_batch=1024, buffer=0, permute=False, data=128,
+            name="configs[4]: scaled shape 128 inds x 128 sites (build-defined networks, one more stride-2 stage), "
+                 "global batch 1024"),
 }
 
 
@@ -230,7 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration: 1 sigGen gp batch 64 (default), 2 tanNorm + normalize, "
-                         "3 div + replay buffer + permute")
+                         "3 div + replay buffer + permute, 4 the scaled 128 x 128 networks at batch 128 per GPU")
     ap.add_argument("--batch", type=int, default=None, help="batch per GPU (default: the configuration's)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="fixed total batch split over the GPUs (strong scaling); with --config 2 / 3 on several GPUs "
@@ -287,13 +309,16 @@ def main():
     from pgan_trainer import FusedTrainer
 
     from pgan_engine import disc_param_shapes, gen_param_shapes
-    ps, pp = synthetic_pool(4096, 20260 + 1 + rank)
+    data = cfg.get("data", 64)
+    ps, pp = synthetic_pool(4096 if data == 64 else 2048, 20260 + 1 + rank, size=data)
+    flop_pa = flop_per_alignment(data, args.critic_iter)
 
     def make_trainer(backend):
         t = FusedTrainer(backend, args.batch, dev, loss=args.loss, act=args.act, critic_iter=args.critic_iter,
-                         seed=1234, rank=rank, world=world, batched_generator=not args.separate_generator_forwards)
+                         seed=1234, rank=rank, world=world, batched_generator=not args.separate_generator_forwards,
+                         data=data)
         gen = torch.Generator().manual_seed(20260)   # identical initial weights on every rank
-        for store, shapes in ((t.eng.G, gen_param_shapes()), (t.eng.D, disc_param_shapes())):
+        for store, shapes in ((t.eng.G, gen_param_shapes(data=data)), (t.eng.D, disc_param_shapes(data))):
             for k, sh in shapes.items():
                 if len(sh) == 1:
                     v = torch.ones(sh) if k.endswith("weight") and not k.startswith("out") else torch.zeros(sh)
@@ -459,7 +484,7 @@ def main():
         nalign = args.critic_iter * args.batch * world * args.steps
         value = nalign / dt
         extras = (f", replay buffer of {buffer_n} batches" if buffer_n else "") + (", row-permuted input" if permute else "")
-        out = dict(metric="train alignments/sec (WGAN-GP step, 64x64)", value=round(value, 2), unit="alignments/sec",
+        out = dict(metric=f"train alignments/sec (WGAN-GP step, {data}x{data})", value=round(value, 2), unit="alignments/sec",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
                    higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
                    arithmetic=("fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
@@ -472,11 +497,11 @@ def main():
                                loss=args.loss, hip_graph=bool(use_graph), launch=route, parallelism=f"dp{world}",
                                batchnorm=("global batch statistics (per-channel sums all-reduced)" if tr.sync_bn
                                           else "per-GPU batch statistics")),
-                   step_tflops=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12, 3),
-                   step_frac_of_fp32_mfma_peak=round(value * FLOP_PER_ALIGNMENT[args.loss] / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+                   step_tflops=round(value * flop_pa / 1e12, 3), flop_per_alignment=flop_pa,
+                   step_frac_of_fp32_mfma_peak=round(value * flop_pa / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
                    roofline=roofline, hbm_kernels=hbm)
-        if world == 1 and x3 and not args.no_fp32_pipe:
+        if world == 1 and x3 and not args.no_fp32_pipe and data == 64:
             # the same step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
             t32 = make_trainer(HipOps(dev, precision="fp32", max_samples=max(1024, 4 * args.batch)))
             n32 = max(5, args.steps // 2)
@@ -497,7 +522,11 @@ def main():
                                          ms_per_step=round(d32 / n32 * 1e3, 4), steps=n32,
                                          note="PGAN_CONV_PRECISION=fp32: all convolutions on the fp32 matrix pipe")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)
+            if data == 64:
+                out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)
+            else:      # bounded sample: a smaller batch of the same networks (the rate per alignment barely depends on it)
+                out["cpu_baseline"] = cpu_baseline(args.loss, args.act, min(args.batch, 16), args.critic_iter, iters=1,
+                                                   data=data, one_thread_batch=2)
         print(json.dumps(out))
     if pg is not None:
         import torch.distributed as dist
