@@ -62,7 +62,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense
 PEAK_HBM_GBS = 8000.0
 # sustained by a register-only MFMA loop on random operands on this part (tools/mfma_peak.hip,
 # tools/mfma_bf16_peak.hip): the clocks drop under data-dependent power
-SUSTAINED_RANDOM_TFLOPS = {"fp32": 92.0, "bf16": 1770.0}
+SUSTAINED_RANDOM_TFLOPS = {"fp32": 92.0, "bf16": 1770.0, "fp16": 1770.0}      # fp16 runs at the bf16 rate
 
 
 def synthetic_pool(n, seed, size=64):
@@ -421,9 +421,11 @@ def main():
             f["flops"] += r["flops"] * r["calls"]
             f["calls"] += r["calls"]
         dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
-        x3 = getattr(ops, "precision", "fp32") == "x3"
+        prec = getattr(ops, "precision", "fp32")
+        x3 = prec in ("x3", "h2")               # split operands on the 16-bit matrix pipe
         wg3 = x3 and getattr(ops, "wgrad_x3", False)
-        pipe = {k: ("bf16" if (x3 and (k != "conv_wgrad" or wg3)) else "fp32") for k in fam}
+        pipe16 = "fp16" if prec == "h2" else "bf16"
+        pipe = {k: (pipe16 if (x3 and (k != "conv_wgrad" or wg3)) else "fp32") for k in fam}
         cname = lambda k: f"{k[0]}[N={k[1]},Cs={k[2]},Cl={k[3]},hs={k[4]}]"
         # bandwidth-bound kernels: algorithmic bytes (tensors read + written once; Adam 28 B per parameter) over the
         # isolated launch duration, against the 8 TB/s HBM peak
@@ -440,7 +442,8 @@ def main():
         if dom:
             f = fam[dom]
             alg = f["flops"] / (f["total_ms"] * 1e-3) / 1e12
-            mult, peak = (6.0, PEAK_BF16_MFMA_TFLOPS) if pipe[dom] == "bf16" else (1.0, PEAK_FP32_MFMA_TFLOPS)
+            mult = {"bf16": 6.0, "fp16": 3.0, "fp32": 1.0}[pipe[dom]]      # MFMA products executed per fp32 product
+            peak = PEAK_FP32_MFMA_TFLOPS if pipe[dom] == "fp32" else PEAK_BF16_MFMA_TFLOPS
             ach = alg * mult
             per_shape = {cname(k): dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
                                         tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
@@ -459,19 +462,20 @@ def main():
                     traffic_of = cname(big)
             except (OSError, ValueError):
                 pass
-            kname = dom + "_x3_kernel" if pipe[dom] == "bf16" else dom + "_kernel"
+            kname = dom + "_x3_kernel" if pipe[dom] != "fp32" else dom + "_kernel"
             roofline = dict(bound="mfma", kernel=f"{kname} ({pipe[dom]} matrix pipe, implicit GEMM)",
                             achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             traffic=traffic, traffic_shape=traffic_of, traffic_measured_at=traffic_at,
                             algorithmic_tflops=round(alg, 3),
                             algorithmic_frac_of_fp32_mfma_peak=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
-                            note=("achieved / peak / frac price the bf16 MFMA work actually executed (6 partial products "
-                                  "per fp32 product) against the dense bf16 peak; algorithmic_* price the fp32 convolution "
-                                  "flops (2 N Cs Cl 16 hs^2 per launch) against the fp32 matrix pipe's 157.3 TFLOP/s"
-                                  if pipe[dom] == "bf16" else "fp32 convolution flops on the fp32 matrix pipe"),
+                            note=(f"achieved / peak / frac price the {pipe[dom]} MFMA work actually executed ({mult:g} partial "
+                                  "products per fp32 product) against the dense 16-bit matrix peak; algorithmic_* price the "
+                                  "fp32 convolution flops (2 N Cs Cl 16 hs^2 per launch) against the fp32 matrix pipe's "
+                                  "157.3 TFLOP/s" if pipe[dom] != "fp32" else "fp32 convolution flops on the fp32 matrix pipe"),
                             executed_per_algorithmic_flop=mult,
                             sustained_on_random_operands=SUSTAINED_RANDOM_TFLOPS[pipe[dom]],
                             frac_of_sustained=round(ach / SUSTAINED_RANDOM_TFLOPS[pipe[dom]], 4),
+                            algorithmic_ceiling_tflops=round(SUSTAINED_RANDOM_TFLOPS[pipe[dom]] / mult, 1),
                             avg_launch_us=round(f["total_ms"] * 1e3 / f["calls"], 2), launches=f["calls"],
                             flops_per_launch_avg=f["flops"] / f["calls"],
                             measured=f"HIP events on the launch stream around {args.profile_iters} back-to-back launches "
@@ -487,9 +491,12 @@ def main():
         out = dict(metric=f"train alignments/sec (WGAN-GP step, {data}x{data})", value=round(value, 2), unit="alignments/sec",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
                    higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
-                   arithmetic=("fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
-                               "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe"
-                               if x3 else "fp32 throughout (fp32 matrix pipe)"),
+                   arithmetic={"h2": "fp32 storage and accumulation; 4x4 convolution products as three exact fp16 partial products "
+                                     "(two-plane split with per-block power-of-two scaling, operand error below 2^-22) on the "
+                                     "16-bit matrix pipe",
+                               "x3": "fp32 storage and accumulation; 4x4 convolution products as six exact bf16 partial products "
+                                     "(3-way split, error below an fp32 multiply's rounding) on the bf16 matrix pipe",
+                               "fp32": "fp32 throughout (fp32 matrix pipe)"}[prec],
                    config=dict(workload=f"{cfg['name']} -- run as {args.act} generator"
                                         f"{' + normalize' if args.act == 'tanh' else ''}, {args.loss} loss, batch {args.batch}/GPU"
                                         f"{extras}, {args.critic_iter} critic + 1 generator step per step",
@@ -502,25 +509,32 @@ def main():
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
                    roofline=roofline, hbm_kernels=hbm)
         if world == 1 and x3 and not args.no_fp32_pipe and data == 64:
-            # the same step with every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), for reference
-            t32 = make_trainer(HipOps(dev, precision="fp32", max_samples=max(1024, 4 * args.batch)))
-            n32 = max(5, args.steps // 2)
-            if best == "graph":
-                t32.capture()
-            elif best == "tape":
-                t32.record_tape()
-            step32 = {"graph": t32.replay, "tape": t32.replay_tape, "eager": t32.iteration}[best]
-            for _ in range(3):
-                step32()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n32):
-                step32()
-            torch.cuda.synchronize()
-            d32 = time.perf_counter() - t1
-            out["fp32_pipe_only"] = dict(value=round(args.critic_iter * args.batch * n32 / d32, 2), unit="alignments/sec",
-                                         ms_per_step=round(d32 / n32 * 1e3, 4), steps=n32,
-                                         note="PGAN_CONV_PRECISION=fp32: all convolutions on the fp32 matrix pipe")
+            # the same step with the other arithmetic choices, for reference: three bf16 planes / six products, and
+            # every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32)
+            for other, label in (("x3", "bf16_split"), ("fp32", "fp32_pipe_only")):
+                if other == prec:
+                    continue
+                t32 = make_trainer(HipOps(dev, precision=other, max_samples=max(1024, 4 * args.batch)))
+                n32 = max(5, args.steps // 2)
+                if best == "graph":
+                    t32.capture()
+                elif best == "tape":
+                    t32.record_tape()
+                step32 = {"graph": t32.replay, "tape": t32.replay_tape, "eager": t32.iteration}[best]
+                for _ in range(3):
+                    step32()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n32):
+                    step32()
+                torch.cuda.synchronize()
+                d32 = time.perf_counter() - t1
+                out[label] = dict(value=round(args.critic_iter * args.batch * n32 / d32, 2), unit="alignments/sec",
+                                  ms_per_step=round(d32 / n32 * 1e3, 4), steps=n32,
+                                  note=f"PGAN_CONV_PRECISION={other}: " + ("three bf16 planes, six products per fp32 product"
+                                                                          if other == "x3" else
+                                                                          "all convolutions on the fp32 matrix pipe"))
+                del t32
         if world == 1 and not args.no_cpu_baseline:
             if data == 64:
                 out["cpu_baseline"] = cpu_baseline(args.loss, args.act, args.batch, args.critic_iter)

@@ -30,9 +30,51 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// (x, y) -> three packed bf16 pairs; low half belongs to x.
-__device__ __forceinline__ void split3(float x, float y, uint32_t (&p)[3]) {
+// ------------------------------------------------------------------------------------------------
+// Two ways of splitting an fp32 operand, chosen at compile time (this source is compiled twice):
+//   default          three bf16 planes, six products            -> entry points pgan_conv_*_x3
+//   PGAN_SPLIT_F16   two fp16 planes, three products            -> entry points pgan_conv_*_h2
+// fp16 carries 11 significant bits: x = h1 + 2^-11 h2 with h1 = fp16(x), h2 = fp16(2^11 (x - h1)) leaves a
+// residual below 2^-22 |x|, and x y = h1 g1 + 2^-11 (h1 g2 + h2 g1) drops only h2 g2 <= 2^-22 |x y|: fp32-class
+// accuracy (about the error of an fp32 MFMA dot product) from half the matrix work and two thirds of the operand
+// traffic.  Storing the second plane scaled by 2^11 keeps it in the range of the first, so only the magnitude of x
+// itself has to fit fp16's exponent range: operands are scaled by a power of two chosen from their largest
+// magnitude (exact, undone on the accumulators).
+// ------------------------------------------------------------------------------------------------
+#ifdef PGAN_SPLIT_F16
+constexpr int NPL = 2;
+constexpr bool F16 = true;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define FN_PREP_BYTES pgan_conv_h2_prep_bytes
+#define FN_PREP pgan_conv_h2_prep
+#define FN_SET_OPTION pgan_h2_set_option
+#define FN_DOWN pgan_conv_down_h2
+#define FN_UP pgan_conv_up_h2
+#define FN_WGRAD_WS pgan_conv_wgrad_h2_workspace_floats
+#define FN_WGRAD pgan_conv_wgrad_h2
+#else
+constexpr int NPL = 3;
+constexpr bool F16 = false;
+#define FN_PREP_BYTES pgan_conv_x3_prep_bytes
+#define FN_PREP pgan_conv_x3_prep
+#define FN_SET_OPTION pgan_x3_set_option
+#define FN_DOWN pgan_conv_down_x3
+#define FN_UP pgan_conv_up_x3
+#define FN_WGRAD_WS pgan_conv_wgrad_x3_workspace_floats
+#define FN_WGRAD pgan_conv_wgrad_x3
+#endif
+constexpr float LO_SCALE = 2048.f;      // 2^11: the second fp16 plane is stored times this
+
+// (x, y) -> NPL packed 16-bit pairs; low half belongs to x.
+__device__ __forceinline__ void split3(float x, float y, uint32_t (&p)[NPL]) {
     f32x2 v = {x, y};
+#ifdef PGAN_SPLIT_F16
+    const f16x2 h1 = __builtin_convertvector(v, f16x2);
+    p[0] = __builtin_bit_cast(uint32_t, h1);
+    const f32x2 r = (v - __builtin_convertvector(h1, f32x2)) * LO_SCALE;
+    p[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+#else
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -42,24 +84,75 @@ __device__ __forceinline__ void split3(float x, float y, uint32_t (&p)[3]) {
             v.y -= __builtin_bit_cast(float, u & 0xffff0000u);
         }
     }
+#endif
 }
 
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_16(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef PGAN_SPLIT_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
-// The six significant partial products of (a1+a2+a3)(b1+b2+b3).  The leading term a1*b1 has its own
+// The significant partial products of the split operands.  The leading term a1*b1 has its own
 // accumulator: the matrix pipe truncates (toward -inf) the bits of a product that fall below the
 // accumulator's last place, so correction terms added straight into the large sum would each lose up to
-// 2^-9 of their value in one direction -- a bias that grows with K (measured -2.7e-7 relative at
-// K = 4096 against -1e-9 with the split accumulators, and a 2.5x larger rms error).
-__device__ __forceinline__ void mfma_x3(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16& hi, f32x16& lo) {
-    lo = mfma_bf16(a[2], b[0], lo);
-    lo = mfma_bf16(a[0], b[2], lo);
-    lo = mfma_bf16(a[1], b[1], lo);
-    lo = mfma_bf16(a[1], b[0], lo);
-    lo = mfma_bf16(a[0], b[1], lo);
-    hi = mfma_bf16(a[0], b[0], hi);
+// 2^-9 of their value in one direction -- a bias that grows with K (bf16: measured -2.7e-7 relative at
+// K = 4096 against -1e-9 with the split accumulators, and a 2.5x larger rms error).  In the fp16 split the
+// correction accumulator also carries the 2^11 of the second planes.
+__device__ __forceinline__ void mfma_x3(const u32x4 (&a)[NPL], const u32x4 (&b)[NPL], f32x16& hi, f32x16& lo) {
+#ifdef PGAN_SPLIT_F16
+    lo = mfma_16(a[1], b[0], lo);
+    lo = mfma_16(a[0], b[1], lo);
+    hi = mfma_16(a[0], b[0], hi);
+#else
+    lo = mfma_16(a[2], b[0], lo);
+    lo = mfma_16(a[0], b[2], lo);
+    lo = mfma_16(a[1], b[1], lo);
+    lo = mfma_16(a[1], b[0], lo);
+    lo = mfma_16(a[0], b[1], lo);
+    hi = mfma_16(a[0], b[0], hi);
+#endif
+}
+// leading-term sum + correction-term sum
+__device__ __forceinline__ float combine(float hi, float lo) { return F16 ? fmaf(lo, 1.f / LO_SCALE, hi) : hi + lo; }
+
+// ---- range of the fp16 split.  An operand set (the activations one block stages over its whole K loop; a weight
+// tensor) is multiplied by 2^-e with e chosen from its largest magnitude so that the scaled values peak in
+// [2^13, 2^14): no overflow (fp16 reaches 2^16), and every element keeps an absolute precision of 2^-36 of that
+// peak through the two planes.  Powers of two: exact; undone on the fp32 results.
+constexpr int WHDR_BYTES = 256;          // header of a prepared-weight buffer: word 0 = bits of the largest |w| seen
+__device__ __forceinline__ int scale_exp(float amax) {
+    const int eb = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu);      // biased exponent, 0 for 0 / subnormal
+    return max(eb - 127 - 13, -126);
+}
+__device__ __forceinline__ float pow2f(int e) {       // 2^e for e in [-126, 127]
+    return __builtin_bit_cast(float, (uint32_t)(min(max(e, -126), 127) + 127) << 23);
+}
+// 2^-e, also for the few e beyond float's exponent range of a single factor
+__device__ __forceinline__ float scaled(float v, int e_neg) { return v * pow2f(-e_neg); }
+// largest of v (>= 0) over the block; sh: LDS scratch of >= blockDim/64 floats, free to reuse after the call
+__device__ __forceinline__ float block_amax(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int nw = (int)(blockDim.x >> 6);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = 0.f;
+    for (int w = 0; w < nw; ++w) m = fmaxf(m, sh[w]);
+    __syncthreads();
+    return m;
+}
+__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ W, uint32_t* __restrict__ hdr, int64_t n4) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(W)[i];
+        m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = block_amax(m, sh);
+    if (threadIdx.x == 0) atomicMax(hdr, __builtin_bit_cast(uint32_t, m));       // non-negative floats order like their bits
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -69,24 +162,26 @@ __device__ __forceinline__ void mfma_x3(const u32x4 (&a)[3], const u32x4 (&b)[3]
 //   up[p][tap][cs/16][cl][cs%16]  UP:   rows cl, one K step = 16 cs at a fixed tap
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, uint16_t* __restrict__ dn,
-                                                   uint16_t* __restrict__ up, int Cs, int Cl) {
+                                                   uint16_t* __restrict__ up, int Cs, int Cl,
+                                                   const uint32_t* __restrict__ whdr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cs * Cl) return;
+    const float sw = F16 ? pow2f(-scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
     const int cs = idx % Cs, cl = idx / Cs;
     const size_t plane = (size_t)Cs * Cl * 16;
     const float* w = W + ((size_t)cs * Cl + cl) * 16;
-    uint32_t pk[3][8];
+    uint32_t pk[NPL][8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 4 * q);
-        uint32_t a[3], b[3];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 4 * q) * sw;
+        uint32_t a[NPL], b[NPL];
         split3(v[0], v[1], a);
         split3(v[2], v[3], b);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { pk[i][2 * q] = a[i]; pk[i][2 * q + 1] = b[i]; }
+        for (int i = 0; i < NPL; ++i) { pk[i][2 * q] = a[i]; pk[i][2 * q + 1] = b[i]; }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         // pk[i][2kh + (kw>>1)] holds taps (kh, kw even | odd): dword order (kh0,kw01) (kh1,kw01) (kh0,kw23) (kh1,kw23)
         u32x4* d = reinterpret_cast<u32x4*>(dn + i * plane + ((size_t)cl * Cs + cs) * 16);
         u32x4 lo = {pk[i][0], pk[i][2], pk[i][1], pk[i][3]}, hi = {pk[i][4], pk[i][6], pk[i][5], pk[i][7]};
@@ -109,14 +204,15 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
 // ------------------------------------------------------------------------------------------------
 template <int HS, int BM, int BN, int CLC>
 __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
-                                                           float* __restrict__ Y, int N, int Cs, int Cl) {
+                                                           float* __restrict__ Y, int N, int Cs, int Cl,
+                                                           const uint32_t* __restrict__ whdr) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
     constexpr int PR = 2 * R + 2, PCW = WS + 1, RSW = PCW + 1;    // patch rows; column pairs per row; their padded count
     constexpr int CHW = SEG * PR * RSW;                           // dwords per channel per plane
     constexpr int BPL = CLC * CHW;
-    constexpr int BUF = 3 * BPL;
+    constexpr int BUF = NPL * BPL;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PE = SEG * PR * PCW, NQ = (PE + 255) / 256;
     constexpr int S = CLC * TM * TN;            // micro steps (six MFMAs each) per chunk
@@ -151,6 +247,8 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
         loff[q] = (e < PE) ? ((seg * PR + pr) >> 1) * (2 * RSW) + 2 * pw + (pr & 1) : 2 * PCW;
     }
     float breg[2][CLC][NQ][2];
+    float sx = 1.f;        // fp16 split: the block's activations are staged times this power of two (2^-ex)
+    int ex = 0;
     auto gload = [&](auto setc, int cl0) {
         constexpr int ST = decltype(setc)::value;
 #pragma unroll
@@ -167,10 +265,10 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
     auto stage = [&](auto setc, auto itc, uint32_t* buf) {
         constexpr int ST = decltype(setc)::value, it = decltype(itc)::value;
         constexpr int c = it / NQ, q = it % NQ;
-        uint32_t p[3];
-        split3(val0[q] ? breg[ST][c][q][0] : 0.f, val1[q] ? breg[ST][c][q][1] : 0.f, p);
+        uint32_t p[NPL];
+        split3(val0[q] ? breg[ST][c][q][0] * sx : 0.f, val1[q] ? breg[ST][c][q][1] * sx : 0.f, p);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) buf[i * BPL + c * CHW + loff[q]] = p[i];
+        for (int i = 0; i < NPL; ++i) buf[i * BPL + c * CHW + loff[q]] = p[i];
     };
 
     uint32_t abase[TM];
@@ -191,7 +289,7 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; acl[tm][tn][r] = 0.f; }
 
-    u32x4 a[2][TM][3], bo[2][TN][3];
+    u32x4 a[2][TM][NPL], bo[2][TN][NPL];
     const size_t wplane = (size_t)Cl * Cs * 16;
     auto aload = [&](auto setc, int cl) {          // weight fragments of channel cl
         constexpr int set = decltype(setc)::value;
@@ -199,14 +297,14 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(Wc + i * wplane + abase[tm]);
+            for (int i = 0; i < NPL; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(Wc + i * wplane + abase[tm]);
     };
     auto ldops = [&](const uint32_t* buf, auto cc) {
         constexpr int c = decltype(cc)::value, set = c & 1;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NPL; ++i) {
                 const u32x2* p = reinterpret_cast<const u32x2*>(buf + i * BPL + c * CHW + bbase[tn]);
                 const u32x2 lo = p[0], hi = p[1];
                 u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
@@ -234,6 +332,20 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
         });
     };
 
+    // fp16 split: one pass over this block's patches for their largest magnitude -> the block's scale
+    if constexpr (F16) {
+        float m = 0.f;
+        for (int kc = 0; kc < nk; ++kc) {
+            gload(IC<0>{}, chunk_cl(kc));
+#pragma unroll
+            for (int c = 0; c < CLC; ++c)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    m = fmaxf(m, fmaxf(val0[q] ? fabsf(breg[0][c][q][0]) : 0.f, val1[q] ? fabsf(breg[0][c][q][1]) : 0.f));
+        }
+        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds)));
+        sx = pow2f(-ex);
+    }
     // prologue: chunk 0 into buffer 0, chunk 1 into register set 0, first weight fragments
     gload(IC<0>{}, chunk_cl(0));
     aload(IC<0>{}, kc0 * CLC);
@@ -251,6 +363,8 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
         __syncthreads();
     }
 
+    // fp16 split: undo the two scales (a product of two in-range powers of two)
+    const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = wn * (BN / 2) + tn * 32 + j;
@@ -263,7 +377,7 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
             for (int r = 0; r < 16; ++r) {
                 const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float* dst = Y + (((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow;
-                const float v = acc[tm][tn][r] + acl[tm][tn][r];
+                const float v = combine(acc[tm][tn][r], acl[tm][tn][r]) * unscale;
                 if (gridDim.y > 1) atomicAdd(dst, v);
                 else *dst = v;
             }
@@ -283,7 +397,7 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
 template <int HS, int BN, int NC>
 __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl,
-                                                              int cl_major) {
+                                                              int cl_major, const uint32_t* __restrict__ whdr) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -291,7 +405,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     constexpr int BM = 32 * NC, TN = BN / 32, NT = 256 * NC;
     constexpr int BPL = NP * 8;                                     // dwords per plane
     constexpr int NI = NP * 2, NQ = (NI + NT - 1) / NT;             // (pixel, channel octet) items per thread
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * 3 * BPL];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * NPL * BPL];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
@@ -319,6 +433,8 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         blds[q] = (e < NI) ? p * 8 + ((oct ^ (p >> 2)) & 1) * 4 : -1;
     }
     float breg[NQ][8];
+    float sx = 1.f;        // fp16 split: the block's activations are staged times this power of two (2^-ex)
+    int ex = 0;
     auto gload = [&](int cs0) {
         const float* Yc = Y + (int64_t)cs0 * HS * WS;
 #pragma unroll
@@ -329,16 +445,17 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     auto lstore = [&](uint32_t* Bs) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            uint32_t pk[3][4];
+            uint32_t pk[NPL][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint32_t p3[3];
-                split3(bval[q] ? breg[q][2 * i] : 0.f, bval[q] ? breg[q][2 * i + 1] : 0.f, p3);
-                pk[0][i] = p3[0]; pk[1][i] = p3[1]; pk[2][i] = p3[2];
+                uint32_t p3[NPL];
+                split3(bval[q] ? breg[q][2 * i] * sx : 0.f, bval[q] ? breg[q][2 * i + 1] * sx : 0.f, p3);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) pk[pl][i] = p3[pl];
             }
             if (blds[q] >= 0) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     u32x4 v = {pk[i][0], pk[i][1], pk[i][2], pk[i][3]};
                     *reinterpret_cast<u32x4*>(Bs + i * BPL + blds[q]) = v;
                 }
@@ -373,12 +490,24 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 
     // gridDim.y > 1: the cs range is split across blocks, which then add into a zeroed X
     const int nk = Cs / (16 * (int)gridDim.y), k0 = blockIdx.y * nk;
-    u32x4 a[4][3];
+    u32x4 a[4][NPL];
     auto aload = [&](int t, int ks) {                 // weight fragments of tap t, K step ks
         const uint16_t* Wk = WP + (size_t)ks * Cl * 16;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
+        for (int i = 0; i < NPL; ++i) a[t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
     };
+    if constexpr (F16) {       // one pass over this block's patches for their largest magnitude -> the block's scale
+        float m = 0.f;
+        for (int kc = 0; kc < nk; ++kc) {
+            gload((k0 + kc) * 16);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m = fmaxf(m, bval[q] ? fabsf(breg[q][i]) : 0.f);
+        }
+        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds)));
+        sx = pow2f(-ex);
+    }
     gload(k0 * 16);
 #pragma unroll
     for (int t = 0; t < 4; ++t) aload(t, k0);
@@ -386,16 +515,16 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     if (nk > 1) gload((k0 + 1) * 16);
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
-        const uint32_t* Bs = lds + (kc & 1) * 3 * BPL;
-        uint32_t* Bn = lds + ((kc + 1) & 1) * 3 * BPL;
+        const uint32_t* Bs = lds + (kc & 1) * NPL * BPL;
+        uint32_t* Bn = lds + ((kc + 1) & 1) * NPL * BPL;
         const int knext = k0 + min(kc + 1, nk - 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            u32x4 bo[TN][3];
+            u32x4 bo[TN][NPL];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
+                for (int i = 0; i < NPL; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) mfma_x3(a[t], bo[tn], acc[tn], acl[tn]);
             aload(t, knext);
@@ -405,6 +534,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         __syncthreads();
     }
 
+    const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = tn * 32 + j;
@@ -415,8 +545,8 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         for (int r = 0; r < 16; ++r) {
             const int cl = cl0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float* dst = X + (((int64_t)n * Cl + cl) * HL + 2 * (oh0 + al) + ph) * WL + 2 * bl + pw;
-            if (gridDim.y > 1) atomicAdd(dst, acc[tn][r] + acl[tn][r]);
-            else *dst = acc[tn][r] + acl[tn][r];
+            if (gridDim.y > 1) atomicAdd(dst, combine(acc[tn][r], acl[tn][r]) * unscale);
+            else *dst = combine(acc[tn][r], acl[tn][r]) * unscale;
         }
     }
 }
@@ -445,7 +575,7 @@ struct WgGeom {
     static constexpr int KWB = PRR * SR + ((PRR * SR / 16) % 2 == 0 && HS >= 16 ? 16 : 0);
     static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB;        // bytes per (segment,) channel
     static constexpr int BPL = (HS == 4) ? SEG * CLB * CHB : CLB * CHB;
-    static constexpr int LDS_BYTES = 3 * APL + 3 * BPL;
+    static constexpr int LDS_BYTES = NPL * APL + NPL * BPL;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
     // staging items of the L side
     static constexpr int NIB = (HS == 4) ? SEG * CLB * 4 * 4 : CLB * PRR * (WS / 2);
@@ -463,7 +593,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
     constexpr int NQB = G::NQB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
     unsigned char* As = lds;
-    unsigned char* Bs = lds + 3 * G::APL;
+    unsigned char* Bs = lds + NPL * G::APL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
@@ -484,6 +614,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         a_lds[q] = row * G::ARS + p * 2;
     }
     f32x4 areg[AV];
+    float sa = 1.f, sb = 1.f;      // fp16 split: scales of the block's S rows and L patches (2^-ea, 2^-eb)
+    int ea = 0, eb = 0;
     // L side items
     constexpr int NBR = (HS == 4) ? 8 : 6;            // raw floats per item
     float breg[NQB][NBR];
@@ -528,11 +660,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
     auto lstore = [&]() {
 #pragma unroll
         for (int q = 0; q < AV; ++q) {
-            uint32_t pa[3], pb[3];
-            split3(areg[q][0], areg[q][1], pa);
-            split3(areg[q][2], areg[q][3], pb);
+            uint32_t pa[NPL], pb[NPL];
+            split3(areg[q][0] * sa, areg[q][1] * sa, pa);
+            split3(areg[q][2] * sa, areg[q][3] * sa, pb);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NPL; ++i) {
                 u32x2 v = {pa[i], pb[i]};
                 *reinterpret_cast<u32x2*>(As + i * G::APL + a_lds[q]) = v;
             }
@@ -543,14 +675,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             if (e >= G::NIB) continue;
             if constexpr (HS == 4) {
                 const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
-                uint32_t s01[3], s23[3], s45[3], s67[3];
-                split3(breg[q][0], breg[q][1], s01);
-                split3(breg[q][2], breg[q][3], s23);
-                split3(breg[q][4], breg[q][5], s45);
-                split3(breg[q][6], breg[q][7], s67);
+                uint32_t s01[NPL], s23[NPL], s45[NPL], s67[NPL];
+                split3(breg[q][0] * sb, breg[q][1] * sb, s01);
+                split3(breg[q][2] * sb, breg[q][3] * sb, s23);
+                split3(breg[q][4] * sb, breg[q][5] * sb, s45);
+                split3(breg[q][6] * sb, breg[q][7] * sb, s67);
                 unsigned char* base = Bs + ((seg * CLB + ch) * 16 + kh * 4) * 32 + (((oh >> 1) ^ (kh & 1)) * 2 + (oh & 1)) * 8;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     // values at input columns 2ow-1+kw for ow = 0..3: kw 0: (-,1,3,5)  1: (0,2,4,6)  2: (1,3,5,7)  3: (2,4,6,-)
                     const u32x2 k0 = {s01[i] & 0xffff0000u, (s23[i] >> 16) | (s45[i] & 0xffff0000u)};
                     const u32x2 k1 = {(s01[i] & 0xffffu) | (s23[i] << 16), (s45[i] & 0xffffu) | (s67[i] << 16)};
@@ -565,13 +697,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             } else {
                 constexpr int ND = WS / 2;
                 const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
-                uint32_t s01[3], s23[3], s45[3];
-                split3(breg[q][0], breg[q][1], s01);
-                split3(breg[q][2], breg[q][3], s23);
-                split3(breg[q][4], breg[q][5], s45);
+                uint32_t s01[NPL], s23[NPL], s45[NPL];
+                split3(breg[q][0] * sb, breg[q][1] * sb, s01);
+                split3(breg[q][2] * sb, breg[q][3] * sb, s23);
+                split3(breg[q][4] * sb, breg[q][5] * sb, s45);
                 unsigned char* base = Bs + ch * G::CHB + r * G::SR + d * 4;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     // plane kw, positions (2d, 2d+1) = input columns (4d-1+kw, 4d+1+kw)
                     unsigned char* b = base + i * G::BPL;
                     *reinterpret_cast<uint32_t*>(b) = (s01[i] & 0xffffu) | (s23[i] << 16);
@@ -605,6 +737,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[tn][r] = 0.f; acl[tn][r] = 0.f; }
 
+    if constexpr (F16) {       // one pass over this block's chunks for the largest magnitude of each operand
+        float ma = 0.f, mb = 0.f;
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            gload(ch);
+#pragma unroll
+            for (int q = 0; q < AV; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ma = fmaxf(ma, fabsf(areg[q][i]));
+#pragma unroll
+            for (int q = 0; q < NQB; ++q)
+#pragma unroll
+                for (int i = 0; i < NBR; ++i) mb = fmaxf(mb, fabsf(breg[q][i]));
+        }
+        ea = scale_exp(block_amax(ma, reinterpret_cast<float*>(lds)));
+        eb = scale_exp(block_amax(mb, reinterpret_cast<float*>(lds)));
+        sa = pow2f(-ea);
+        sb = pow2f(-eb);
+    }
     if (c_begin < c_end) gload(c_begin);
     for (int ch = c_begin; ch < c_end; ++ch) {
         lstore();
@@ -612,13 +762,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         if (ch + 1 < c_end) gload(ch + 1);
 #pragma unroll
         for (int s = 0; s < PIXC / 16; ++s) {
-            u32x4 a[3], bo[2][3];
+            u32x4 a[NPL], bo[2][NPL];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + i * G::APL + abase + s * 32);
+            for (int i = 0; i < NPL; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + i * G::APL + abase + s * 32);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < NPL; ++i)
                     bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * G::BPL + bbase[tn] + bstep(s));
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) mfma_x3(a, bo[tn], acc[tn], acl[tn]);
@@ -626,6 +776,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         __syncthreads();
     }
 
+    const float unscale = F16 ? pow2f(ea) * pow2f(eb) : 1.f;
     float* out = slab + (int64_t)blockIdx.y * Cs * Cl * 16;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -633,7 +784,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int cs = cs0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int cl = cl0 + wn * 4 + tn * 2 + (j >> 4);
-            out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = acc[tn][r] + acl[tn][r];
+            out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = combine(acc[tn][r], acl[tn][r]) * unscale;
         }
 }
 
@@ -675,10 +826,11 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
 }
 
 template <int HS, int BM, int BN, int CLC>
-int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st) {
+int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
+                     const uint32_t* whdr) {
     if (Cs % BM || Cl % (2 * CLC * ks)) return PGAN_EINVAL;
     const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), ks);
-    conv_down_x3_kernel<HS, BM, BN, CLC><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl);
+    conv_down_x3_kernel<HS, BM, BN, CLC><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
     return pgan_launch_status();
 }
 
@@ -686,7 +838,7 @@ int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0, g_up_ks = 0;   // tuning ov
 int g_up_order = 0;                                                 // 1: pixel-major, 2: row-tile-major block order
 
 template <int HS>
-int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st) {
+int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr) {
     if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     int variant = g_dn_variant, ks = g_dn_ks;
     if (variant == 0 || ks < 1) {
@@ -701,19 +853,19 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
     }
     if (ks > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
     switch (variant) {
-        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st);
-        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st);
-        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st);
-        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st);
+        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
+        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
+        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
+        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
         default: return PGAN_EINVAL;
     }
 }
 
 template <int HS>
-int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int Cl, hipStream_t st) {
+int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr) {
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
     if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
-    const uint16_t* up = WP + (size_t)3 * Cs * Cl * 16;
+    const uint16_t* up = WP + (size_t)NPL * Cs * Cl * 16;
     // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU, and always at hs = 4 (measured
     // 135 against 149 us at N = 320; the 64-pixel tile spills there unless its occupancy drops to 2 waves per SIMD)
     int variant = g_up_variant ? g_up_variant : ((HS == 4 || (Cl / 32) * PixTile<HS, 64>::ntiles(N) < 512) ? 5 : 1);
@@ -727,11 +879,11 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     const dim3 g(blocks, ks);
     const int clm = g_up_order ? g_up_order - 1 : ((int64_t)Cs * Cl * 96 > (int64_t)N * Cs * HS * HS * 4);
     switch (variant) {
-        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
-        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
-        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
-        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
-        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm); break;
+        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
+        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
+        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
+        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
+        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
         default: return PGAN_EINVAL;
     }
     return pgan_launch_status();
@@ -741,7 +893,7 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
 
 extern "C" {
 
-int pgan_x3_set_option(const char* name, int value) {
+int FN_SET_OPTION(const char* name, int value) {
     if (!name) return PGAN_EINVAL;
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, "down_variant") && value >= 0 && value <= 4) { g_dn_variant = value; return PGAN_OK; }
@@ -754,44 +906,53 @@ int pgan_x3_set_option(const char* name, int value) {
 }
 
 // Bytes of the prepared-weight buffer for W[Cs][Cl][4][4].
-long long pgan_conv_x3_prep_bytes(int Cs, int Cl) { return (long long)Cs * Cl * 16 * 2 * 6; }
+long long FN_PREP_BYTES(int Cs, int Cl) { return (long long)Cs * Cl * 16 * 2 * 2 * NPL + (F16 ? WHDR_BYTES : 0); }
 
 // Split W[Cs][Cl][4][4] (fp32) into the bf16 planes the x3 kernels read.  Run again whenever W changes.
-int pgan_conv_x3_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st) {
+int FN_PREP(const float* W, void* planes, int Cs, int Cl, hipStream_t st) {
     if (Cs <= 0 || Cl <= 0) return PGAN_EINVAL;
-    uint16_t* dn = static_cast<uint16_t*>(planes);
-    prep_kernel<<<(Cs * Cl + 255) / 256, 256, 0, st>>>(W, dn, dn + (size_t)3 * Cs * Cl * 16, Cs, Cl);
+    // fp16 split: the buffer starts with a header whose first word holds (the bits of) the largest |w| ever prepared
+    // into it -- zero it once when the buffer is created; it only grows, which keeps the scale safe and stable
+    uint32_t* hdr = F16 ? static_cast<uint32_t*>(planes) : nullptr;
+    uint16_t* dn = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
+    if (F16) {
+        const int64_t n4 = (int64_t)Cs * Cl * 4;
+        weight_amax_kernel<<<(int)((n4 + 1023) / 1024 < 256 ? (n4 + 1023) / 1024 : 256), 256, 0, st>>>(W, hdr, n4);
+    }
+    prep_kernel<<<(Cs * Cl + 255) / 256, 256, 0, st>>>(W, dn, dn + (size_t)NPL * Cs * Cl * 16, Cs, Cl, hdr);
     return pgan_launch_status();
 }
 
 // S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W, stride 2, pad 1) with W given as prepared planes.  H = hs.
-int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
+int FN_DOWN(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
-    const uint16_t* wp = static_cast<const uint16_t*>(planes);
+    const uint32_t* hdr = F16 ? static_cast<const uint32_t*>(planes) : nullptr;
+    const uint16_t* wp = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
     switch (hs) {
-        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st);
-        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st);
-        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st);
-        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st);
+        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st, hdr);
+        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st, hdr);
+        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st, hdr);
+        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st, hdr);
         default: return PGAN_EINVAL;
     }
 }
 
 // L[N,Cl,2H,2H] = conv_transpose2d(S[N,Cs,H,H], W, stride 2, pad 1) with W given as prepared planes.
-int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st) {
+int FN_UP(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
-    const uint16_t* wp = static_cast<const uint16_t*>(planes);
+    const uint32_t* hdr = F16 ? static_cast<const uint32_t*>(planes) : nullptr;
+    const uint16_t* wp = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
     switch (hs) {
-        case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st);
-        case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st);
-        case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st);
-        case 32: return launch_up<32>(S, wp, L, N, Cs, Cl, st);
+        case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st, hdr);
+        case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st, hdr);
+        case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st, hdr);
+        case 32: return launch_up<32>(S, wp, L, N, Cs, Cl, st, hdr);
         default: return PGAN_EINVAL;
     }
 }
 
 // Scratch floats pgan_conv_wgrad_x3 needs for these dimensions.
-long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs) {
+long long FN_WGRAD_WS(int N, int Cs, int Cl, int hs) {
     int ns = 1;
     switch (hs) {
         case 4: ns = wgrad_x3_splits<4>(N, Cs, Cl); break;
@@ -804,7 +965,7 @@ long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs) {
 }
 
 // dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)] as pgan_conv_wgrad, with the six-product bf16 split of both operands.
-int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+int FN_WGRAD(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
                        int hs, int n_keep, int n_swap, int accumulate, hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
     switch (hs) {

@@ -248,8 +248,8 @@ class Engine:
         stale = getattr(ops, "invalidate_weight_planes", None)
         if stale is not None:
             for st in (self.D, self.G):
-                stale(st.flat)
-                st.on_load.append(lambda st=st: stale(st.flat))
+                stale(st.flat, reset=True)
+                st.on_load.append(lambda st=st: stale(st.flat, reset=True))
         self.g_batches_tracked = 0   # every BatchNorm of the generator sees the same count
         # data parallel with batch statistics over all ranks' samples: bn_sync(partial sums, float64) adds them over
         # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch

@@ -40,6 +40,10 @@ _SIGS = {
     "pgan_conv_down_x3": [P, P, P, I, I, I, I, P],
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
     "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P],
+    "pgan_conv_h2_prep": [P, P, I, I, P],
+    "pgan_conv_down_h2": [P, P, P, I, I, I, I, P],
+    "pgan_conv_up_h2": [P, P, P, I, I, I, I, P],
+    "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
@@ -86,7 +90,8 @@ _SIGS = {
     "pgan_step_graph_destroy": [P],
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
-                                "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats",
+                                "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats", "pgan_h2_set_option",
+                                "pgan_conv_h2_prep_bytes", "pgan_conv_wgrad_h2_workspace_floats",
                                 "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials",
                                 "pgan_bn_fwd_partials", "pgan_gn_fwd_static_max_samples"])
 for _name, _args in _SIGS.items():
@@ -105,11 +110,13 @@ _lib.pgan_gn_fwd_static_max_samples.argtypes = []
 _lib.pgan_gn_fwd_static_max_samples.restype = c_int
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
-_lib.pgan_conv_wgrad_x3_workspace_floats.argtypes = [I, I, I, I]
-_lib.pgan_conv_wgrad_x3_workspace_floats.restype = c_longlong
-_lib.pgan_conv_x3_prep_bytes.argtypes = [I, I]
-_lib.pgan_conv_x3_prep_bytes.restype = c_longlong
-for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option):
+for _fn in (_lib.pgan_conv_wgrad_x3_workspace_floats, _lib.pgan_conv_wgrad_h2_workspace_floats):
+    _fn.argtypes = [I, I, I, I]
+    _fn.restype = c_longlong
+for _fn in (_lib.pgan_conv_x3_prep_bytes, _lib.pgan_conv_h2_prep_bytes):
+    _fn.argtypes = [I, I]
+    _fn.restype = c_longlong
+for _fn in (_lib.pgan_set_option, _lib.pgan_x3_set_option, _lib.pgan_h2_set_option):
     _fn.argtypes = [ctypes.c_char_p, c_int]
     _fn.restype = c_int
 
@@ -158,8 +165,9 @@ def set_option(name: str, value: int) -> None:
 
 
 def set_x3_option(name: str, value: int) -> None:
-    """Tile override of the bf16-pipe convolution kernels for tuning runs (0 = size-based choice)."""
+    """Tile override of the split-operand convolution kernels (both splits) for tuning runs (0 = size-based choice)."""
     _check(_lib.pgan_x3_set_option(name.encode(), int(value)), f"pgan_x3_set_option({name}, {value})")
+    _check(_lib.pgan_h2_set_option(name.encode(), int(value)), f"pgan_h2_set_option({name}, {value})")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -258,9 +266,10 @@ class HipOps:
         self._hold = False
         self._keep = []   # host-side arrays that must outlive an enqueue call
         # "x3": 4x4 convolutions as six exact bf16 partial products per fp32 product on the bf16 matrix pipe
-        # (fp32 accuracy); "fp32": the fp32 matrix pipe.  PGAN_CONV_PRECISION overrides the default.
-        self.precision = precision or os.environ.get("PGAN_CONV_PRECISION", "x3")
-        if self.precision not in ("x3", "fp32"):
+        # (fp32 accuracy); "h2": three products of a two-plane fp16 split on the same pipe; "fp32": the fp32 matrix
+        # pipe.  PGAN_CONV_PRECISION overrides the default.
+        self.precision = precision or os.environ.get("PGAN_CONV_PRECISION", "h2")
+        if self.precision not in ("x3", "h2", "fp32"):
             raise PganError(f"unknown convolution precision {self.precision!r}")
         # prepared bf16 planes per weight tensor; static_weights = the caller promises to call
         # invalidate_weight_planes() after every weight update (otherwise planes are rebuilt per call)
@@ -268,30 +277,43 @@ class HipOps:
         self.static_weights = False
         self.wgrad_x3 = os.environ.get("PGAN_WGRAD_X3", "1") != "0"     # weight gradients on the bf16 pipe too
 
-    def invalidate_weight_planes(self, within: Optional[torch.Tensor] = None):
-        """Mark prepared weight copies stale: all of them, or those whose weights live inside `within`."""
-        if within is None:
-            for ent in self._planes.values():
+    def invalidate_weight_planes(self, within: Optional[torch.Tensor] = None, reset: bool = False):
+        """Mark prepared weight copies stale: all of them, or those whose weights live inside `within`.
+        reset: the weights may be unrelated to the ones prepared before (a load, another tensor at the same address), so
+        the fp16 split's running record of their largest magnitude starts again; without it (an optimizer step) the
+        record is kept, which holds the scale steady."""
+        lo = hi = None
+        if within is not None:
+            lo = within.data_ptr()
+            hi = lo + within.numel() * within.element_size()
+        for key, ent in self._planes.items():
+            if lo is None or lo <= key[0] < hi:
                 ent[1] = False
-            return
-        lo = within.data_ptr()
-        hi = lo + within.numel() * within.element_size()
-        for (ptr, _, _), ent in self._planes.items():
-            if lo <= ptr < hi:
-                ent[1] = False
+                ent[2] = ent[2] or reset
+
+    @property
+    def split(self) -> bool:
+        """Convolutions run on split operands (prepared weight planes) rather than on the fp32 matrix pipe."""
+        return self.precision in ("x3", "h2")
 
     def _weight_planes(self, w):
         Cs, Cl = w.shape[0], w.shape[1]
-        key = (w.data_ptr(), Cs, Cl)
+        h2 = self.precision == "h2"
+        key = (w.data_ptr(), Cs, Cl, h2)
         ent = self._planes.get(key)
         if ent is None:
             if self.capturing:
                 raise PganError("weight planes were first requested inside a graph capture")
-            nbytes = _lib.pgan_conv_x3_prep_bytes(Cs, Cl)
-            ent = [torch.empty(nbytes, dtype=torch.uint8, device=self.device), False]
+            nbytes = (_lib.pgan_conv_h2_prep_bytes if h2 else _lib.pgan_conv_x3_prep_bytes)(Cs, Cl)
+            ent = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device), False, False]   # [planes, fresh, reset]
             self._planes[key] = ent
-        if not (ent[1] and (self.static_weights or self._hold)):
-            _check(_lib.pgan_conv_x3_prep(_ptr(w), ent[0].data_ptr(), Cs, Cl, _stream()), "pgan_conv_x3_prep")
+        keep = self.static_weights or self._hold
+        if not (ent[1] and keep):
+            if h2 and (ent[2] or not keep):      # header word 0: largest |w| prepared so far (see pgan_conv_h2_prep)
+                ent[0][:4].zero_()
+            ent[2] = False
+            prep = _lib.pgan_conv_h2_prep if h2 else _lib.pgan_conv_x3_prep
+            _check(prep(_ptr(w), ent[0].data_ptr(), Cs, Cl, _stream()), "pgan_conv_prep")
             ent[1] = True
         return ent[0].data_ptr()
 
@@ -300,9 +322,9 @@ class HipOps:
         N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
         Cs, hs = w.shape[0], HL // 2
         assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
-        if self.precision == "x3" and Cl > 1:
-            _check(_lib.pgan_conv_down_x3(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, _stream()),
-                   "pgan_conv_down_x3")
+        if self.split and Cl > 1:
+            fn = _lib.pgan_conv_down_h2 if self.precision == "h2" else _lib.pgan_conv_down_x3
+            _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down (split)")
             return
         _check(_lib.pgan_conv_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down")
 
@@ -310,9 +332,9 @@ class HipOps:
         N, Cs, hs = y.shape[0], y.shape[1], y.shape[2]
         Cl = w.shape[1]
         assert tuple(x.shape) == (N, Cl, 2 * hs, 2 * hs) and w.shape[0] == Cs
-        if self.precision == "x3" and Cl > 1 and act == 0:
-            _check(_lib.pgan_conv_up_x3(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, _stream()),
-                   "pgan_conv_up_x3")
+        if self.split and Cl > 1 and act == 0:
+            fn = _lib.pgan_conv_up_h2 if self.precision == "h2" else _lib.pgan_conv_up_x3
+            _check(fn(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, _stream()), "pgan_conv_up (split)")
             return
         _check(_lib.pgan_conv_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, hs, act, _stream()), "pgan_conv_up")
 
@@ -322,12 +344,14 @@ class HipOps:
         if n_keep is None:
             n_keep = N
         assert tuple(dw.shape[:2]) == (Cs, Cl) and x.shape[0] >= N and x.shape[2] == 2 * hs
-        if self.precision == "x3" and self.wgrad_x3 and Cl > 1:
-            need = _lib.pgan_conv_wgrad_x3_workspace_floats(N, Cs, Cl, hs)
+        if self.split and self.wgrad_x3 and Cl > 1:
+            h2 = self.precision == "h2"
+            need = (_lib.pgan_conv_wgrad_h2_workspace_floats if h2 else _lib.pgan_conv_wgrad_x3_workspace_floats)(N, Cs, Cl, hs)
             if need < 0 or need > self.ws.numel():
                 raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
-            _check(_lib.pgan_conv_wgrad_x3(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs,
-                                           n_keep, n_swap, int(accumulate), _stream()), "pgan_conv_wgrad_x3")
+            fn = _lib.pgan_conv_wgrad_h2 if h2 else _lib.pgan_conv_wgrad_x3
+            _check(fn(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs, n_keep, n_swap,
+                      int(accumulate), _stream()), "pgan_conv_wgrad (split)")
             return
         need = _lib.pgan_conv_wgrad_workspace_floats(N, Cs, Cl, hs)
         if need < 0 or need > self.ws.numel():
@@ -382,7 +406,7 @@ class HipOps:
     def prepare_weights(self, weights) -> None:
         """Build the prepared copies of these convolution weights now, on the current stream, so that later uses on
         several streams (all ordered after this point) find them ready."""
-        if self.precision == "x3":
+        if self.split:
             self._hold = False
             for w in weights:
                 if w.shape[1] > 1:

@@ -100,7 +100,7 @@ class FusedTrainer:
     def weights_changed(self) -> None:
         """Tell the op backend that parameters were written outside the engine's optimizer steps."""
         if hasattr(self.ops, "invalidate_weight_planes"):
-            self.ops.invalidate_weight_planes()
+            self.ops.invalidate_weight_planes(reset=True)
         self.graph = None
         self.tape = None
 

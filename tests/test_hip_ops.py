@@ -18,7 +18,7 @@ RTOL = 1e-5
 @pytest.fixture(scope="module")
 def hip():
     from pgan_hip import HipOps
-    return HipOps(torch.device("cuda:0"))
+    return HipOps(torch.device("cuda:0"), precision="x3")      # the split-kernel tests switch to "h2" themselves
 
 
 REF = TorchOps()
@@ -73,8 +73,10 @@ def test_conv_down(hip, Cs, Cl, hs, N, kg):
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N", [5, 8])
 @pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (2, 1), (2, 2), (3, 1), (4, 1), (4, 4)])
-def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
-    """Six-product bf16 split on the bf16 matrix pipe: same fp32 tolerance as the fp32-pipe kernels."""
+@pytest.mark.parametrize("split", ["x3", "h2"])
+def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks, split):
+    """Split operands on the 16-bit matrix pipe (six products of three bf16 planes / three products of two fp16
+    planes): same fp32 tolerance as the fp32-pipe kernels."""
     from pgan_hip import set_x3_option
     if Cs % 128 and variant in (1, 2):
         pytest.skip("128-row tiles need Cs % 128 == 0")
@@ -84,6 +86,7 @@ def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
     REF.conv_down(*d64(x, w), want)
     got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
     assert hip.precision == "x3"
+    hip.precision = split
     set_x3_option("down_variant", variant)
     set_x3_option("down_ks", ks)
     try:
@@ -91,6 +94,7 @@ def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
     finally:
         set_x3_option("down_variant", 0)
         set_x3_option("down_ks", 0)
+        hip.precision = "x3"
     close("conv_down_x3", got, want)
 
 
@@ -117,7 +121,8 @@ def test_conv_up(hip, Cs, Cl, hs, N, mode):
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N", [5, 8])
 @pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2), (3, 1), (4, 1), (5, 1)])
-def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
+@pytest.mark.parametrize("split", ["x3", "h2"])
+def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks, split):
     from pgan_hip import set_x3_option
     rng = np.random.default_rng(2)
     y, w = rnd(rng, N, Cs, hs, hs), rnd(rng, Cs, Cl, 4, 4, scale=0.05)
@@ -126,20 +131,32 @@ def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks):
     got = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
     set_x3_option("up_variant", variant)
     set_x3_option("up_ks", ks)
+    hip.precision = split
     try:
         hip.conv_up(*gpu(y, w), got)
     finally:
         set_x3_option("up_variant", 0)
         set_x3_option("up_ks", 0)
+        hip.precision = "x3"
     close("conv_up_x3", got, want)
 
 
-def test_bf16_pipe_extremes(hip):
-    """The split keeps fp32's exponent range: tiny and huge magnitudes, exact zeros, and weights that are
-    updated in place between calls (prepared planes must follow them)."""
+@pytest.mark.parametrize("split", ["x3", "h2"])
+def test_bf16_pipe_extremes(hip, split):
+    """Both splits keep fp32's exponent range (bf16 has it; the fp16 planes are scaled per block and per weight
+    tensor): tiny and huge magnitudes, samples of very different magnitude side by side, exact zeros, and weights that
+    are updated in place between calls (prepared planes must follow them)."""
     rng = np.random.default_rng(12)
     N, Cs, Cl, hs = 3, 128, 64, 16
-    for scale_x, scale_w in [(1e-18, 1e-12), (1e15, 1e12), (1.0, 0.0)]:
+    hip.precision = split
+    try:
+        _extremes(hip, rng, N, Cs, Cl, hs)
+    finally:
+        hip.precision = "x3"
+
+
+def _extremes(hip, rng, N, Cs, Cl, hs):
+    for scale_x, scale_w in [(1e-18, 1e-12), (1e15, 1e12), (1.0, 0.0), (3e-7, 2.0)]:
         x, w = rnd(rng, N, Cl, 2 * hs, 2 * hs, scale=scale_x), rnd(rng, Cs, Cl, 4, 4, scale=scale_w)
         want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
         REF.conv_down(*d64(x, w), want)
@@ -158,11 +175,32 @@ def test_bf16_pipe_extremes(hip):
     want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
     REF.conv_down(x.double(), -2.0 * w.double(), want)
     close("conv_down_x3 after in-place weight update", got, want)
+    # samples whose magnitudes differ by 2^40: every sample keeps its own relative accuracy, in all three kernels
+    mags = torch.tensor([1e-6, 1.0, 1e6]).view(N, 1, 1, 1)
+    x, y = rnd(rng, N, Cl, 2 * hs, 2 * hs) * mags, rnd(rng, N, Cs, hs, hs) * mags
+    w = rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+    REF.conv_down(*d64(x, w), want)
+    got = torch.empty(N, Cs, hs, hs, device=DEV)
+    hip.conv_down(*gpu(x, w), got)
+    wantu = torch.zeros(N, Cl, 2 * hs, 2 * hs, dtype=torch.float64)
+    REF.conv_up(*d64(y, w), wantu)
+    gotu = torch.empty(N, Cl, 2 * hs, 2 * hs, device=DEV)
+    hip.conv_up(*gpu(y, w), gotu)
+    for n in range(N):
+        close(f"conv_down sample of magnitude {float(mags[n]):g}", got[n], want[n])
+        close(f"conv_up sample of magnitude {float(mags[n]):g}", gotu[n], wantu[n])
+    for a, b in ((x / mags, y), (x, y / mags), (x * 1e-20, y * 1e-12)):      # weight gradient: one operand, then both, spread out
+        wantw = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
+        REF.conv_wgrad(*d64(b, a), wantw, N, 0)
+        gotw = torch.empty(Cs, Cl, 4, 4, device=DEV)
+        hip.conv_wgrad(*gpu(b, a), gotw)
+        close("conv_wgrad over samples of different magnitude", gotw, wantw)
 
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (12, 0, 6), (33, 11, 11)])
-@pytest.mark.parametrize("pipe", ["fp32", "bf16"])
+@pytest.mark.parametrize("pipe", ["fp32", "bf16", "h2"])
 def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
     if hs == 32 and pipe == "fp32":
         pytest.skip("the 128 x 128 stage exists on the bf16 pipe only")
@@ -171,7 +209,8 @@ def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
     want = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
     REF.conv_wgrad(*d64(ya, x), want, keep, swap)
     got = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
-    hip.wgrad_x3 = pipe == "bf16"
+    hip.wgrad_x3 = pipe != "fp32"
+    hip.precision = "h2" if pipe == "h2" else "x3"
     base = rnd(rng, Cs, Cl, 4, 4)
     acc = base.to(DEV)
     try:
@@ -179,6 +218,7 @@ def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
         hip.conv_wgrad(*gpu(ya, x), acc, keep, swap, accumulate=True)
     finally:
         hip.wgrad_x3 = True
+        hip.precision = "x3"
     close("conv_wgrad", got, want)
     close("conv_wgrad.accumulate", acc, want + base.double())
 
