@@ -276,6 +276,8 @@ def main():
                     help="one untimed iteration to collect the launch shapes, then only the isolated per-shape timing "
                          "(the command to put under rocprofv3 --kernel-trace --stats when comparing its per-kernel "
                          "average durations with roofline.per_shape)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-variant override of the split-operand convolutions for comparison runs; may repeat")
     args = ap.parse_args()
     if args.kernels_only:
         args.steps, args.warmup, args.no_graph, args.no_cpu_baseline, args.no_fp32_pipe = 1, 0, True, True, True
@@ -334,6 +336,10 @@ def main():
         return t
 
     ops = HipOps(dev, max_samples=max(1024, 4 * args.batch))
+    for item in args.opt:
+        import pgan_hip
+        name, value = item.split("=")
+        pgan_hip.set_x3_option(name, int(value))
     timed = RecordingOps(ops)
     tr = make_trainer(timed)
     if use_dist:

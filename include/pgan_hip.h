@@ -69,6 +69,25 @@ int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, lon
  * "wg_target" = blocks the weight-gradient split aims at; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
 
+/* ---- The same convolutions with two fp16 planes per operand and three partial products per fp32 product
+ * (x = h1 + 2^-11 h2; the dropped h2*g2 term is below 2^-22 |x y|): half the matrix work of the bf16 split at the
+ * accuracy of an fp32 dot product.  fp16's narrow exponent range is handled inside the calls by exact power-of-two
+ * scaling: every block scales the activations it stages by their own largest magnitude, a weight tensor by the
+ * largest |w| its planes buffer has seen.  That running maximum lives in the first 256 bytes of the planes buffer:
+ *   planes = device buffer of pgan_conv_h2_prep_bytes(Cs, Cl) bytes, ZEROED once by the caller before its first
+ *   pgan_conv_h2_prep (and zeroed again to forget the history, e.g. after loading other weights); every
+ *   pgan_conv_h2_prep(W, ...) raises the maximum to max|W| and rewrites the planes; prepare again whenever W changes.
+ * Argument lists, layouts, return codes and the reference ops are those of the _x3 calls above
+ * (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32). */
+long long pgan_conv_h2_prep_bytes(int Cs, int Cl);
+int pgan_conv_h2_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
+int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
+int pgan_conv_up_h2(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st);
+long long pgan_conv_wgrad_h2_workspace_floats(int N, int Cs, int Cl, int hs);
+int pgan_conv_wgrad_h2(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
+                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
+int pgan_h2_set_option(const char* name, int value);
+
 /* up to 4 such reductions in one launch (the norm-parameter gradients of the four stages) */
 int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const* out, const int* C, int nseg, int r0,
                            int r1, int r2, int r3, hipStream_t st);

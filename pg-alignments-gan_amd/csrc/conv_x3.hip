@@ -202,8 +202,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
 // with one barrier per chunk of CLC channels: chunk k+1 goes from registers to LDS (split on the way)
 // between the MFMAs of chunk k while chunk k+2 is in flight from global memory into a second register set.
 // ------------------------------------------------------------------------------------------------
-template <int HS, int BM, int BN, int CLC>
-__global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
+// KG = 2: two groups of four waves share the block's output tile and take alternate halves of the block's channel
+// range, each with its own LDS buffers; group 1 hands its sums to group 0 through LDS at the end (a fixed order:
+// deterministic).  gridDim.y = 2 splits the range once more over two blocks that add into a zeroed Y -- two
+// addends, so the result does not depend on which block comes first.
+template <int HS, int BM, int BN, int CLC, int KG>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl,
                                                            const uint32_t* __restrict__ whdr) {
     using T = PixTile<HS, BN>;
@@ -218,9 +222,12 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
     constexpr int S = CLC * TM * TN;            // micro steps (six MFMAs each) per chunk
     constexpr int NST = CLC * NQ;               // staging items per thread per chunk
     static_assert(BM % 64 == 0 && BN % 64 == 0 && CLC % 2 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * BUF];
+    constexpr int LDS_WORDS = (KG > 1 && BM * BN > 2 * BUF * KG) ? BM * BN : 2 * BUF * KG;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[LDS_WORDS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = (KG > 1) ? (int)(threadIdx.x >> 8) : 0;
+    uint32_t* const lds = lds_all + grp * 2 * BUF;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
     const int nmt = Cs / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
@@ -313,8 +320,8 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
     };
 
     // gridDim.y > 1: the channel range is also split across blocks, which then add into a zeroed Y
-    const int nk = Cl / (CLC * (int)gridDim.y);       // even (checked by the launcher)
-    const int kc0 = blockIdx.y * nk;
+    const int nk = Cl / (CLC * (int)gridDim.y * KG);       // even (checked by the launcher)
+    const int kc0 = ((int)blockIdx.y * KG + grp) * nk;
     const int cl_last = (kc0 + nk) * CLC - 1;
     auto chunk_cl = [&](int kc) { return (kc0 + (kc < nk ? kc : nk - 1)) * CLC; };
 
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
                 for (int q = 0; q < NQ; ++q)
                     m = fmaxf(m, fmaxf(val0[q] ? fabsf(breg[0][c][q][0]) : 0.f, val1[q] ? fabsf(breg[0][c][q][1]) : 0.f));
         }
-        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds)));
+        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds_all)));      // one scale for the whole block
         sx = pow2f(-ex);
     }
     // prologue: chunk 0 into buffer 0, chunk 1 into register set 0, first weight fragments
@@ -365,6 +372,20 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
 
     // fp16 split: undo the two scales (a product of two in-range powers of two)
     const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
+    if constexpr (KG > 1) {       // group 1 -> LDS -> group 0 (the K loop ended on a barrier: the buffers are free)
+        float* xch = reinterpret_cast<float*>(lds_all);
+        if (grp == 1) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xch[((tm * TN + tn) * 16 + r) * 256 + tid] = combine(acc[tm][tn][r], acl[tm][tn][r]);
+        }
+        __syncthreads();
+        if (grp == 1) return;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = wn * (BN / 2) + tn * 32 + j;
@@ -377,7 +398,9 @@ __global__ __launch_bounds__(256, (BN == 64) ? 3 : 2) void conv_down_x3_kernel(c
             for (int r = 0; r < 16; ++r) {
                 const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float* dst = Y + (((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow;
-                const float v = combine(acc[tm][tn][r], acl[tm][tn][r]) * unscale;
+                float v = combine(acc[tm][tn][r], acl[tm][tn][r]);
+                if constexpr (KG > 1) v += reinterpret_cast<const float*>(lds_all)[((tm * TN + tn) * 16 + r) * 256 + tid];
+                v *= unscale;
                 if (gridDim.y > 1) atomicAdd(dst, v);
                 else *dst = v;
             }
@@ -825,12 +848,16 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
     return pgan_launch_status();
 }
 
+// ks: 1 | 2 (blocks along K, two-addend sums) | 4 (two blocks of two wave groups each)
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
                      const uint32_t* whdr) {
-    if (Cs % BM || Cl % (2 * CLC * ks)) return PGAN_EINVAL;
-    const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), ks);
-    conv_down_x3_kernel<HS, BM, BN, CLC><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
+    if (Cs % BM || Cl % (2 * CLC * ks) || (ks != 1 && ks != 2 && ks != 4)) return PGAN_EINVAL;
+    const int gy = ks > 1 ? 2 : 1;
+    if (gy > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
+    const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), gy);
+    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
+    else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
     return pgan_launch_status();
 }
 
@@ -847,11 +874,12 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
         const int b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
         int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
         if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
+        else if (Cs % 128 == 0 && b4 >= 512 && Cl >= 256) { v = 2; k = 2; }      // long K: 128x64 tiles, K over two blocks
         while (k > 1 && Cl % (8 * k)) k >>= 1;
         if (variant == 0) variant = v;
         if (ks < 1) ks = k;
     }
-    if (ks > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
+    if (ks == 3 || ks > 4) return PGAN_EINVAL;
     switch (variant) {
         case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
         case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);

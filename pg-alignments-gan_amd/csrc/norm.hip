@@ -15,16 +15,23 @@
 namespace {
 
 
-// Adds v into sh[c] after reducing it over the GL consecutive lanes that share channel c.
+// Adds v into this wave's row of sh[i] (CW rows of 64 channels, one row per wave of the block) at channel c after
+// reducing it over the GL consecutive lanes that share the channel.  Rows are private to a wave and the lanes that
+// write hold different channels, so no atomics are needed and the sums do not depend on the waves' timing; the caller
+// adds the rows in a fixed order (channel_total) after a barrier.
+constexpr int CW = 4;
 template <int NV>
 __device__ __forceinline__ void channel_accumulate(float (&v)[NV], float* const (&sh)[NV], int c, int GL) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float x = v[i];
         for (int o = 1; o < GL; o <<= 1) x += __shfl_xor(x, o, 64);
-        if ((lane & (GL - 1)) == 0) atomicAdd(&sh[i][c], x);
+        if ((lane & (GL - 1)) == 0) sh[i][wave * 64 + c] += x;
     }
+}
+__device__ __forceinline__ float channel_total(const float* sh, int c) {
+    return (sh[c] + sh[64 + c]) + (sh[128 + c] + sh[192 + c]);
 }
 
 // Every GroupNorm op is two launches over (sample, slice) blocks, SL slices per sample so that small batches
@@ -113,14 +120,14 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
                                                   float* __restrict__ pb, double* __restrict__ ws, int M, int HW, int C,
                                                   int pld) {
     __shared__ double sh[2 * ST / 64];
-    __shared__ float cg[64], cb[64];
+    __shared__ float cg[CW * 64], cb[CW * 64];
     const Slice sl(M, C);
     const int GL = min(64, HW / 4), cps = C / SL;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
     const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
-    for (int c = sl.tid; c < cps; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
+    for (int c = sl.tid; c < CW * 64; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
     __syncthreads();
     float sw = 0.f, swx = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
@@ -140,10 +147,10 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
         channel_accumulate<2>(pe, dst, cl, GL);
     }
     double red[2] = {sw, swx};
-    put_partials<2>(red, sh, ws, sl);   // its barriers also order the LDS atomics before the reads below
+    put_partials<2>(red, sh, ws, sl);   // its barriers also order the per-wave channel rows before the reads below
     for (int c = sl.tid; c < cps; c += ST) {
-        pg[(int64_t)sl.n * pld + sl.c0 + c] = cg[c];
-        pb[(int64_t)sl.n * pld + sl.c0 + c] = cb[c];
+        pg[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cg, c);
+        pb[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cb, c);
     }
 }
 __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, const float* __restrict__ h,
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
                                                    float* __restrict__ pg, float* __restrict__ pb,
                                                    double* __restrict__ ws, int M, int HW, int C, int pld) {
     __shared__ double sh[3 * ST / 64];
-    __shared__ float cg[64], cb[64];
+    __shared__ float cg[CW * 64], cb[CW * 64];
     const Slice sl(M, C);
     const int GL = min(64, HW / 4), cps = C / SL;
     const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     const float tb = stats_t[2 * sl.n], c_ = stats_t[2 * sl.n + 1];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int c = sl.tid; c < cps; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
+    for (int c = sl.tid; c < CW * 64; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
     __syncthreads();
     float sq = 0.f, sqx = 0.f, swt = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
@@ -275,8 +282,8 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
     double red[3] = {sq, sqx, swt};
     put_partials<3>(red, sh, ws, sl);
     for (int c = sl.tid; c < cps; c += ST) {
-        pg[(int64_t)sl.n * pld + sl.c0 + c] = cg[c];
-        pb[(int64_t)sl.n * pld + sl.c0 + c] = cb[c];
+        pg[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cg, c);
+        pb[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cb, c);
     }
 }
 __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hbar, const float* __restrict__ u,

@@ -24,6 +24,7 @@ the penalised samples, then ONE weight-gradient pass per layer over all 4B sampl
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -164,7 +165,9 @@ class SideStream:
         # higher-class hardware queue blocked on an event of a lower-class queue kept that queue from being served).
         self.enabled = torch.device(device).type == "cuda"
         if self.enabled:
-            self.stream = torch.cuda.Stream(device=device)
+            # PGAN_SERIAL_STREAMS=1 (debugging aid): every side stream is the caller's stream, so nothing overlaps
+            serial = os.environ.get("PGAN_SERIAL_STREAMS", "0") == "1"
+            self.stream = torch.cuda.current_stream(device) if serial else torch.cuda.Stream(device=device)
             self.mark = torch.cuda.Event()
 
     # The waits go through pgan_tape.call: a launch tape being recorded notes them with the stream objects of now.
@@ -255,7 +258,6 @@ class Engine:
         # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch
         self.bn_sync = None
         self.bn_world = 1
-        import os
         self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
         # weight gradients of the Wasserstein samples right after their backward, the penalised samples' share added
         # later (two half-size passes per stage instead of one): measured slightly slower, kept as an option

@@ -23,3 +23,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """Every GPU test starts with NaN in the memory its torch.empty tensors will get (see helpers.poison_gpu_cache)."""
+    if "gpu" in request.keywords:
+        import torch
+        if torch.cuda.is_available():
+            from helpers import poison_gpu_cache
+            poison_gpu_cache()
+    yield

@@ -58,3 +58,15 @@ def max_rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     b = b.detach().to("cpu", torch.float64)
     rms = float(b.pow(2).mean().sqrt())
     return float((a - b).abs().max()) / (rms if rms > 0 else 1.0)
+
+
+def poison_gpu_cache(device=None, mbytes: int = 768) -> None:
+    """Fill the blocks torch's caching allocator will hand out next with NaN: a large block and a run of small ones are
+    written and freed, so later torch.empty tensors start as NaN instead of as whatever (often zeros) the driver or an
+    earlier test left there.  A kernel that reads memory nothing wrote then shows up as NaN, not as a rare mismatch."""
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    big = torch.full((mbytes << 18,), float("nan"), device=dev)
+    small = [torch.full((1 << 16,), float("nan"), device=dev) for _ in range(512)]        # 256 KB each: the small pools
+    tiny = [torch.full((256,), float("nan"), device=dev) for _ in range(2048)]
+    torch.cuda.synchronize(dev)
+    del big, small, tiny

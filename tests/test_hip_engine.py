@@ -310,8 +310,8 @@ def test_two_chain_critic_step_equals_single_chain(hip):
 @pytest.mark.parametrize("loss", ["gp", "div"])
 def test_trainer_routes_agree(hip, loss):
     """FusedTrainer: eager iterations, hipGraph replay and launch-tape replay enqueue the same kernels on the same
-    streams -- same device RNG draws, same pool cursor, same losses, and weights equal up to the +-lr steps that
-    rounding noise (split-K atomics) gives entries with noise-level gradients."""
+    streams -- same device RNG draws, same pool cursor, and, every kernel's sums being taken in a fixed order (K splits
+    are in-block or two-addend), bit-identical losses, weights and running statistics."""
     from pgan_trainer import FusedTrainer
     B, n_it, lr = 8, 3, 5e-5
     rs, rp = orc.synthetic_alignments(64, 9)
@@ -334,12 +334,9 @@ def test_trainer_routes_agree(hip, loss):
     for route in ("graph", "tape"):
         b = out[route]
         assert b["cursor"] == a["cursor"] and torch.equal(b["rng"], a["rng"]) and b["nb"] == a["nb"] and b["step"] == a["step"]
-        for x, y in zip(a["losses"], b["losses"]):
-            assert abs(x - y) <= 1e-2 * max(1.0, abs(x)), (route, a["losses"], b["losses"])
-        for k in ("d", "g"):
-            assert float((a[k] - b[k]).abs().max()) <= 2 * lr * 2 * n_it, (route, k)
-            assert rel_err(b[k], a[k]) < 1e-3, (route, k)
-        assert torch.allclose(a["run"], b["run"], rtol=1e-3, atol=2 * lr * 2 * n_it)      # follows the weights' +-lr steps
+        assert tuple(a["losses"]) == tuple(b["losses"]), (route, a["losses"], b["losses"])
+        for k in ("d", "g", "run"):
+            assert torch.equal(a[k], b[k]), (route, k, rel_err(b[k], a[k]))
 
 
 @pytest.mark.parametrize("act", ["sigmoid", "tanh"])

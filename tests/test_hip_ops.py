@@ -253,7 +253,7 @@ def test_conv_c1(hip, N, act, Cs, hs):
 GN_SHAPES = [(64, 32), (128, 16), (256, 8), (512, 4), (32, 64)]
 
 
-@pytest.mark.parametrize("C,hs", GN_SHAPES)
+@pytest.mark.parametrize("C,hs", GN_SHAPES + [(256, 4)])
 def test_groupnorm_family(hip, C, hs):
     rng = np.random.default_rng(5)
     N = 3

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 B = 8
+SEED = int(os.environ.get("PGAN_DP_SEED", "60"))
 
 
 def _inputs(seed):
@@ -58,6 +59,8 @@ def _worker(rank, world, port, loss, out_dir, backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    from helpers import poison_gpu_cache
+    poison_gpu_cache(dev, 256)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -65,7 +68,7 @@ def _worker(rank, world, port, loss, out_dir, backend="gloo"):
     tr = FusedTrainer(HipOps(dev), B // world, dev, loss=loss, process_group=dist.group.WORLD, rank=rank, world=world)
     assert tr.sync_bn
     _load(tr)
-    rs, rp, t, z = _inputs(60)
+    rs, rp, t, z = _inputs(SEED)
     # rank r holds the global batch's rows [r B/2, (r+1) B/2); generator_grads sees them flipped within the rank
     out = _run(tr, rs, rp, t, z, slice(rank * B // world, (rank + 1) * B // world), dev)
     for k in ("closs", "gloss"):
@@ -94,7 +97,7 @@ def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss, backend)
     dev = torch.device("cuda", 0)
     tr = FusedTrainer(HipOps(dev), B, dev, loss=loss)
     _load(tr)
-    rs, rp, t, z = _inputs(60)
+    rs, rp, t, z = _inputs(SEED)
     e = tr.eng
     e.critic_grads(rs.to(dev), rp.to(dev), z.to(dev), t.to(dev) if loss == "gp" else None)
     want_d, want_closs = e.D.gflat.clone().cpu(), e.closs.clone().cpu()
@@ -104,7 +107,15 @@ def test_two_ranks_equal_one_process_at_the_whole_batch(tmp_path, loss, backend)
 
     def rel(a, b):
         return float((a - b).norm() / b.norm())
-    assert rel(got["d"], want_d) < 1e-5, rel(got["d"], want_d)
+    def per_tensor(store, a, b):       # which parameters disagree, for the failure message
+        out = {}
+        for k, off in store.offsets.items():
+            n = store.p[k].numel()
+            r = float((a[off:off + n] - b[off:off + n]).norm() / max(float(b[off:off + n].norm()), 1e-30))
+            if r > 1e-6:
+                out[k] = r
+        return out
+    assert rel(got["d"], want_d) < 1e-5, (rel(got["d"], want_d), per_tensor(e.D, got["d"], want_d))
     assert torch.allclose(got["closs"], want_closs, rtol=2e-5, atol=1e-6)
     assert rel(got["g"], e.G.gflat.cpu()) < 1e-5, rel(got["g"], e.G.gflat.cpu())
     assert torch.allclose(got["gloss"], e.gloss.cpu().reshape(-1), rtol=2e-5, atol=1e-6)
