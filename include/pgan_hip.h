@@ -59,12 +59,17 @@ int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r
  *   (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32, no fused activation). */
 long long pgan_conv_x3_prep_bytes(int Cs, int Cl);
 int pgan_conv_x3_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
-int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
-int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st);
+/* amax, amax_per_sample, amax_count: optional magnitude bounds of the activation operand, used only by the fp16 split
+ * below (this split ignores them; pass NULL, 0, 0). */
+int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                      int amax_per_sample, int amax_count, hipStream_t st);
+int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,
+                    int amax_per_sample, int amax_count, hipStream_t st);
 /* weight gradient with both operands split in the kernel (same arguments and scratch contract as pgan_conv_wgrad) */
 long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
+                       int hs, int n_keep, int n_swap, int accumulate, const float* amax_s, int amax_s_per_sample,
+                       int amax_s_count, const float* amax_l, int amax_l_per_sample, int amax_l_count, hipStream_t st);
 /* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant", "up_ks", "up_order",
  * "wg_target" = blocks the weight-gradient split aims at; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
@@ -78,14 +83,28 @@ int pgan_x3_set_option(const char* name, int value);
  *   pgan_conv_h2_prep (and zeroed again to forget the history, e.g. after loading other weights); every
  *   pgan_conv_h2_prep(W, ...) raises the maximum to max|W| and rewrites the planes; prepare again whenever W changes.
  * Argument lists, layouts, return codes and the reference ops are those of the _x3 calls above
- * (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32). */
+ * (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32).
+ * Scanning the activations costs a block a pass over its operands before it can stage them (15-30 % of these
+ * kernels' time).  A caller that knows upper bounds of the operand's magnitude -- the norm entry points below
+ * report them for their outputs -- passes them instead:
+ *   amax != NULL, amax_per_sample = k in 1..64: amax[n * k + i], i < k, each bound sample n of the call
+ *     (pgan_gn_* write k = 8 per sample);
+ *   amax != NULL, amax_per_sample = 0: every one of amax[0 .. amax_count) bounds the whole operand
+ *     (pgan_bn_* write one entry per channel);
+ *   amax == NULL: the kernel scans.
+ * Bounds may be loose (a factor 2^k costs k of the 2^28 of dynamic range below the bound); a bound below the true
+ * magnitude can overflow fp16.  The weight-gradient call takes one bound per operand; rows of a per-sample bound of
+ * L follow L's own sample order (the call applies r(n) to them). */
 long long pgan_conv_h2_prep_bytes(int Cs, int Cl);
 int pgan_conv_h2_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
-int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
-int pgan_conv_up_h2(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st);
+int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                      int amax_per_sample, int amax_count, hipStream_t st);
+int pgan_conv_up_h2(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,
+                    int amax_per_sample, int amax_count, hipStream_t st);
 long long pgan_conv_wgrad_h2_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad_h2(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st);
+                       int hs, int n_keep, int n_swap, int accumulate, const float* amax_s, int amax_s_per_sample,
+                       int amax_s_count, const float* amax_l, int amax_l_per_sample, int amax_l_count, hipStream_t st);
 int pgan_h2_set_option(const char* name, int value);
 
 /* up to 4 such reductions in one launch (the norm-parameter gradients of the four stages) */
@@ -95,10 +114,12 @@ int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const
 /* ---- GroupNorm(1,C) + LeakyReLU(0.1), per-sample statistics (src/layers.py:442-443 and the three
  * repeats below it).  a, h, u, d, t, hd, hbar, p: [N][C][HW]; stats*: [N][2]; pg, pb: rows of per-channel sums, row stride pld.
  * C <= 512, C % 8 == 0, HW a power of two >= 16.  ws: scratch of pgan_gn_workspace_bytes(N) bytes (per-slice partial
- * sums; every op is a sums launch plus an apply launch over 8 slices per sample). */
+ * sums; every op is a sums launch plus an apply launch over 8 slices per sample).
+ * amax (every op; may be NULL): [N][8] output, the largest magnitude of each of the 8 slices of every sample of the
+ * op's main output (h, d, hd, p) -- the per-sample bounds the fp16-split convolutions take for that operand. */
 long long pgan_gn_workspace_bytes(int N);
 int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
-                long long ws_bytes, int N, int C, int HW, hipStream_t st);
+                long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* pgan_gn_fwd for callers that cannot allocate device memory or bring a workspace (code under hipGraph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result as pgan_gn_fwd; the
  * slice partial sums live in a fixed array inside the library (384 KiB per GPU, for up to
@@ -111,44 +132,49 @@ int pgan_gn_fwd_static_max_samples(void);
  * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta. */
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
                 float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, void* ws, long long ws_bytes,
-                int N, int C, int HW, hipStream_t st);
+                int N, int C, int HW, float* amax, hipStream_t st);
 /* tangent (JVP) of the same block: hd from the tangent t of a; stats_t = (mean t, mean xhat*t). */
 int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st);
+                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* second-order backward: the piece of autograd's double backward (create_graph=True at
  * src/layers.py:51-53,66-74) that belongs to this block.  hbar may be NULL (= 0). */
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
                  const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st);
+                 void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.1), src/layers.py:93-110,119-135.  a, h: [B][C][HW],
  * HW % 4 == 0; stats: [2][C] = batch mean, rstd; running stats updated in place (unbiased variance). */
 /* ws: scratch of pgan_bn_workspace_bytes(C) bytes (large layers run as a sums launch plus an apply launch over
- * several blocks per channel). */
+ * several blocks per channel).
+ * amax (every op; may be NULL): [C] output, the largest magnitude per channel of the op's main output (h, da) over all
+ * samples and groups of the call -- whole-operand bounds for the fp16-split convolutions (amax_per_sample = 0). */
 long long pgan_bn_workspace_bytes(int C);
 /* groups > 1: a / h hold `groups` consecutive forward passes of B samples each; every pass gets its own batch statistics
  * (stats: [groups][2][C]) and the running statistics step through the passes in order, as `groups` calls would (the
  * generator forwards of one iteration, src/train_wgan_v2.py:535,622, share their weights). */
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
                 float* stats, void* ws, long long ws_bytes, int B, int C, int HW, float momentum, int groups,
-                hipStream_t st);
+                float* amax, hipStream_t st);
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st);
+                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, float* amax,
+                hipStream_t st);
 /* The same layers (src/layers.py:93-110,119-135) with batch statistics over the global batch of a data-parallel run
  * (one process per GPU, B samples each): *_sums writes pgan_bn_partials(B, C, HW) doubles of per-channel partial sums
  * (forward: sum a, sum a^2; backward: sum dy, sum dy xhat), the caller adds them over the ranks (all-reduce), *_apply
  * finishes from the totals with world = number of ranks.  dgamma / dbeta are 1/world of the all-rank totals, so that
- * the later sum of the parameter gradients over the ranks gives the totals. */
+ * the later sum of the parameter gradients over the ranks gives the totals.  amax: *_sums clears the array that the
+ * following *_apply fills (pass the same pointer to both, or NULL to both). */
 long long pgan_bn_partials(int B, int C, int HW);                     /* backward */
 long long pgan_bn_fwd_partials(int B, int C, int HW, int groups);     /* forward */
-int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, hipStream_t st);
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, float* amax, hipStream_t st);
 int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
                       float* stats, const double* part, int B, int C, int HW, int world, float momentum, int groups,
-                      hipStream_t st);
+                      float* amax, hipStream_t st);
 int pgan_bn_bwd_sums(const float* dh, const float* h, const float* a, const float* stats, double* part, int B, int C,
-                     int HW, hipStream_t st);
+                     int HW, float* amax, hipStream_t st);
 int pgan_bn_bwd_apply(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, hipStream_t st);
+                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, float* amax,
+                      hipStream_t st);
 
 /* ---- linear head nn.Linear(11712, 1) over cat(2-D features, 1-D features), src/layers.py:482,491-493 */
 int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float* b, float* score, int N, int K2, int K1,

@@ -144,6 +144,27 @@ __device__ __forceinline__ float block_amax(float v, float* sh) {
     __syncthreads();
     return m;
 }
+// Upper bounds of an activation operand's magnitude supplied by whoever produced it (the norm kernels write them), so
+// that a block need not scan its operands before staging them.  per_sample > 0: p[n * per_sample + i], i < per_sample,
+// bound sample n of the launch; per_sample == 0: every one of p[0 .. count) bounds the whole operand.  p == nullptr:
+// no bounds given, the kernel scans.
+struct Bound {
+    const float* p;
+    int per_sample, count;
+};
+// largest bound over samples [n_lo, n_hi) (mapped through `remap`) as seen by this thread; reduce with block_amax
+template <class F>
+__device__ __forceinline__ float bound_max(const Bound& b, int n_lo, int n_hi, F remap) {
+    float m = 0.f;
+    if (b.per_sample > 0) {
+        const int cnt = (n_hi - n_lo) * b.per_sample;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+            m = fmaxf(m, b.p[(int64_t)remap(n_lo + i / b.per_sample) * b.per_sample + i % b.per_sample]);
+    } else {
+        for (int i = threadIdx.x; i < b.count; i += blockDim.x) m = fmaxf(m, b.p[i]);
+    }
+    return m;
+}
 __global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ W, uint32_t* __restrict__ hdr, int64_t n4) {
     __shared__ float sh[4];
     float m = 0.f;
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
 template <int HS, int BM, int BN, int CLC, int KG>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl,
-                                                           const uint32_t* __restrict__ whdr) {
+                                                           const uint32_t* __restrict__ whdr, Bound bx) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -342,7 +363,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     // fp16 split: one pass over this block's patches for their largest magnitude -> the block's scale
     if constexpr (F16) {
         float m = 0.f;
-        for (int kc = 0; kc < nk; ++kc) {
+        if (bx.p) m = bound_max(bx, n0, min(n0 + SEG, N), [](int n) { return n; });
+        else for (int kc = 0; kc < nk; ++kc) {
             gload(IC<0>{}, chunk_cl(kc));
 #pragma unroll
             for (int c = 0; c < CLC; ++c)
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
 template <int HS, int BN, int NC>
 __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl,
-                                                              int cl_major, const uint32_t* __restrict__ whdr) {
+                                                              int cl_major, const uint32_t* __restrict__ whdr, Bound by) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -521,7 +543,8 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     };
     if constexpr (F16) {       // one pass over this block's patches for their largest magnitude -> the block's scale
         float m = 0.f;
-        for (int kc = 0; kc < nk; ++kc) {
+        if (by.p) m = bound_max(by, n0, min(n0 + SEG, N), [](int n) { return n; });
+        else for (int kc = 0; kc < nk; ++kc) {
             gload((k0 + kc) * 16);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -608,7 +631,7 @@ struct WgGeom {
 template <int HS>
 __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restrict__ YA, const float* __restrict__ X,
                                                             float* __restrict__ slab, int N, int Cs, int Cl, int n_keep,
-                                                            int n_swap, int chunks_per_block) {
+                                                            int n_swap, int chunks_per_block, Bound bs, Bound bl) {
     using G = WgGeom<HS>;
     using T = typename G::T;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, SEG = G::SEG, R = G::R, PIXC = G::PIXC, BM = G::BM, CLB = G::CLB;
@@ -762,7 +785,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
 
     if constexpr (F16) {       // one pass over this block's chunks for the largest magnitude of each operand
         float ma = 0.f, mb = 0.f;
-        for (int ch = c_begin; ch < c_end; ++ch) {
+        int n_lo = 0, n_hi = 0, oh_;
+        if (c_begin < c_end) {      // samples of this block's chunks
+            T::origin(c_begin, n_lo, oh_);
+            T::origin(c_end - 1, n_hi, oh_);
+            n_hi = min(n_hi + SEG, N);
+        }
+        if (bs.p) ma = bound_max(bs, n_lo, n_hi, [](int n) { return n; });
+        if (bl.p) mb = bound_max(bl, n_lo, n_hi, [&](int n) {
+            return (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
+        });
+        if (!bs.p || !bl.p) for (int ch = c_begin; ch < c_end; ++ch) {
             gload(ch);
 #pragma unroll
             for (int q = 0; q < AV; ++q)
@@ -836,14 +869,14 @@ int wgrad_x3_splits(int N, int Cs, int Cl) {
 
 template <int HS>
 int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
-                 int n_keep, int n_swap, int accumulate, hipStream_t st) {
+                 int n_keep, int n_swap, int accumulate, hipStream_t st, Bound bs, Bound bl) {
     if (Cs % 64 || Cl % 8) return PGAN_EINVAL;
     const int chunks = PixTile<HS, 64>::ntiles(N);
     const int ns = wgrad_x3_splits<HS>(N, Cs, Cl);
     const int cpb = (chunks + ns - 1) / ns;
     const int64_t len = (int64_t)Cs * Cl * 16;
     if (ns * len > ws_floats) return PGAN_EINVAL;
-    conv_wgrad_x3_kernel<HS><<<dim3((Cs / 64) * (Cl / 8), ns), 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb);
+    conv_wgrad_x3_kernel<HS><<<dim3((Cs / 64) * (Cl / 8), ns), 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb, bs, bl);
     slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len, accumulate);
     return pgan_launch_status();
 }
@@ -851,13 +884,13 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
 // ks: 1 | 2 (blocks along K, two-addend sums) | 4 (two blocks of two wave groups each)
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
-                     const uint32_t* whdr) {
+                     const uint32_t* whdr, Bound bx) {
     if (Cs % BM || Cl % (2 * CLC * ks) || (ks != 1 && ks != 2 && ks != 4)) return PGAN_EINVAL;
     const int gy = ks > 1 ? 2 : 1;
     if (gy > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), gy);
-    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
-    else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr);
+    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx);
+    else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx);
     return pgan_launch_status();
 }
 
@@ -865,7 +898,8 @@ int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0, g_up_ks = 0;   // tuning ov
 int g_up_order = 0;                                                 // 1: pixel-major, 2: row-tile-major block order
 
 template <int HS>
-int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr) {
+int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
+                Bound bx) {
     if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     int variant = g_dn_variant, ks = g_dn_ks;
     if (variant == 0 || ks < 1) {
@@ -881,16 +915,17 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
     }
     if (ks == 3 || ks > 4) return PGAN_EINVAL;
     switch (variant) {
-        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
-        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
-        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
-        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr);
+        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
+        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
+        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
+        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
         default: return PGAN_EINVAL;
     }
 }
 
 template <int HS>
-int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr) {
+int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
+              Bound by) {
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
     if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     const uint16_t* up = WP + (size_t)NPL * Cs * Cl * 16;
@@ -907,14 +942,19 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     const dim3 g(blocks, ks);
     const int clm = g_up_order ? g_up_order - 1 : ((int64_t)Cs * Cl * 96 > (int64_t)N * Cs * HS * HS * 4);
     switch (variant) {
-        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
-        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
-        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
-        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
-        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr); break;
+        case 1: conv_up_x3_kernel<HS, 64, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 2: conv_up_x3_kernel<HS, 128, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
         default: return PGAN_EINVAL;
     }
     return pgan_launch_status();
+}
+
+// a bound is absent, per-sample (rows of 1..64 entries) or an array of at least one entry
+bool bound_ok(const Bound& b) {
+    return !b.p || (b.per_sample > 0 && b.per_sample <= 64) || (b.per_sample == 0 && b.count > 0);
 }
 
 }  // namespace
@@ -952,29 +992,35 @@ int FN_PREP(const float* W, void* planes, int Cs, int Cl, hipStream_t st) {
 }
 
 // S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W, stride 2, pad 1) with W given as prepared planes.  H = hs.
-int FN_DOWN(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
+int FN_DOWN(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+            int amax_per_sample, int amax_count, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
+    const Bound bx{amax, amax_per_sample, amax_count};
+    if (!bound_ok(bx)) return PGAN_EINVAL;
     const uint32_t* hdr = F16 ? static_cast<const uint32_t*>(planes) : nullptr;
     const uint16_t* wp = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
     switch (hs) {
-        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st, hdr);
-        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st, hdr);
-        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st, hdr);
-        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st, hdr);
+        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st, hdr, bx);
+        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st, hdr, bx);
+        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st, hdr, bx);
+        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st, hdr, bx);
         default: return PGAN_EINVAL;
     }
 }
 
 // L[N,Cl,2H,2H] = conv_transpose2d(S[N,Cs,H,H], W, stride 2, pad 1) with W given as prepared planes.
-int FN_UP(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, hipStream_t st) {
+int FN_UP(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,
+          int amax_per_sample, int amax_count, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
+    const Bound by{amax, amax_per_sample, amax_count};
+    if (!bound_ok(by)) return PGAN_EINVAL;
     const uint32_t* hdr = F16 ? static_cast<const uint32_t*>(planes) : nullptr;
     const uint16_t* wp = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
     switch (hs) {
-        case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st, hdr);
-        case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st, hdr);
-        case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st, hdr);
-        case 32: return launch_up<32>(S, wp, L, N, Cs, Cl, st, hdr);
+        case 4: return launch_up<4>(S, wp, L, N, Cs, Cl, st, hdr, by);
+        case 8: return launch_up<8>(S, wp, L, N, Cs, Cl, st, hdr, by);
+        case 16: return launch_up<16>(S, wp, L, N, Cs, Cl, st, hdr, by);
+        case 32: return launch_up<32>(S, wp, L, N, Cs, Cl, st, hdr, by);
         default: return PGAN_EINVAL;
     }
 }
@@ -993,14 +1039,17 @@ long long FN_WGRAD_WS(int N, int Cs, int Cl, int hs) {
 }
 
 // dW[Cs,Cl,4,4] = sum_n S[n] (x) L[r(n)] as pgan_conv_wgrad, with the six-product bf16 split of both operands.
-int FN_WGRAD(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
-                       int hs, int n_keep, int n_swap, int accumulate, hipStream_t st) {
+int FN_WGRAD(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl, int hs,
+             int n_keep, int n_swap, int accumulate, const float* amax_s, int amax_s_per_sample, int amax_s_count,
+             const float* amax_l, int amax_l_per_sample, int amax_l_count, hipStream_t st) {
     if (N <= 0) return PGAN_EINVAL;
+    const Bound bs{amax_s, amax_s_per_sample, amax_s_count}, bl{amax_l, amax_l_per_sample, amax_l_count};
+    if (!bound_ok(bs) || !bound_ok(bl)) return PGAN_EINVAL;
     switch (hs) {
-        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
-        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
-        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
-        case 32: return launch_wgrad<32>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st);
+        case 4: return launch_wgrad<4>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st, bs, bl);
+        case 8: return launch_wgrad<8>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st, bs, bl);
+        case 16: return launch_wgrad<16>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st, bs, bl);
+        case 32: return launch_wgrad<32>(S, L, dW, ws, ws_floats, N, Cs, Cl, n_keep, n_swap, accumulate, st, bs, bl);
         default: return PGAN_EINVAL;
     }
 }

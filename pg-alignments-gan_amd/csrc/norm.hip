@@ -72,6 +72,20 @@ __device__ __forceinline__ void get_totals(double (&tot)[NV], const double* ws, 
     }
 }
 
+// Largest |value| a block wrote, for the consumers that scale their operands (the fp16-split convolutions): every
+// thread passes the largest magnitude among its outputs; `dst` (may be null) receives the block's.  256-thread blocks.
+__device__ __forceinline__ float block_amax256(float m) {
+    __shared__ float shm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+}
+__device__ __forceinline__ float amax4(float m, const f32x4& o) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+}
+
 __global__ __launch_bounds__(ST) void gn_fwd_sums(const float* __restrict__ a, double* __restrict__ ws, int M, int C) {
     __shared__ double sh[2 * ST / 64];
     const Slice sl(M, C);
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(ST) void gn_fwd_sums(const float* __restrict__ a, d
 __global__ __launch_bounds__(ST) void gn_fwd_apply(const float* __restrict__ a, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ h,
                                                    float* __restrict__ stats, const double* __restrict__ ws, int M,
-                                                   int HW, int C) {
+                                                   int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
     double tot[2];
     get_totals<2>(tot, ws, sl.n);
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(ST) void gn_fwd_apply(const float* __restrict__ a, 
     }
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* h4 = reinterpret_cast<f32x4*>(h + sl.base);
+    float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const int c = sl.c0 + (i * 4) / HW;
         const float g = gamma[c], b = beta[c];
@@ -108,7 +123,12 @@ __global__ __launch_bounds__(ST) void gn_fwd_apply(const float* __restrict__ a, 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + b);
+        am = amax4(am, o);
         h4[i] = o;
+    }
+    if (amax) {      // uniform over the block
+        am = block_amax256(am);
+        if (sl.tid == 0) amax[sl.n * SL + sl.s] = am;
     }
 }
 
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
                                                    const float* __restrict__ a, const float* __restrict__ stats,
                                                    const float* __restrict__ gamma, float* __restrict__ d,
                                                    float* __restrict__ stats_b, const double* __restrict__ ws, int M,
-                                                   int HW, int C) {
+                                                   int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
     double tot[2];
     get_totals<2>(tot, ws, sl.n);
@@ -171,6 +191,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* d4 = reinterpret_cast<f32x4*>(d + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
@@ -180,7 +201,12 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
             const float xh = (av[e] - mu) * r, w = g * lrelu_mask(hv[e]) * uv[e];
             o[e] = r * (w - mw - xh * mwx);
         }
+        am = amax4(am, o);
         d4[i] = o;
+    }
+    if (amax) {      // uniform over the block
+        am = block_amax256(am);
+        if (sl.tid == 0) amax[sl.n * SL + sl.s] = am;
     }
 }
 
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
                                                    const float* __restrict__ a, const float* __restrict__ stats,
                                                    const float* __restrict__ gamma, float* __restrict__ hd,
                                                    float* __restrict__ stats_t, const double* __restrict__ ws, int M,
-                                                   int HW, int C) {
+                                                   int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
     double tot[2];
     get_totals<2>(tot, ws, sl.n);
@@ -222,6 +248,7 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* o4 = reinterpret_cast<f32x4*>(hd + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 tv = t4[i], hv = h4[i], av = a4[i];
@@ -231,7 +258,12 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
             const float xh = (av[e] - mu) * r;
             o[e] = lrelu_mask(hv[e]) * g * (r * (tv[e] - tb - xh * c_));
         }
+        am = amax4(am, o);
         o4[i] = o;
+    }
+    if (amax) {      // uniform over the block
+        am = block_amax256(am);
+        if (sl.tid == 0) amax[sl.n * SL + sl.s] = am;
     }
 }
 
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hb
                                                     const float* __restrict__ a, const float* __restrict__ stats,
                                                     const float* __restrict__ stats_b, const float* __restrict__ stats_t,
                                                     const float* __restrict__ gamma, float* __restrict__ p,
-                                                    const double* __restrict__ ws, int M, int HW, int C) {
+                                                    const double* __restrict__ ws, int M, int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
     double tot[3];
     get_totals<3>(tot, ws, sl.n);
@@ -310,6 +342,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hb
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* p4 = reinterpret_cast<f32x4*>(p + sl.base);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const float g = gamma[sl.c0 + (i * 4) / HW];
         const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
@@ -321,7 +354,12 @@ __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hb
             const float Q = q - r * (c_ * w + mwx * tv[e]);
             o[e] = r * (Q - mQ - xh * kx);
         }
+        am = amax4(am, o);
         p4[i] = o;
+    }
+    if (amax) {      // uniform over the block
+        am = block_amax256(am);
+        if (sl.tid == 0) amax[sl.n * SL + sl.s] = am;
     }
 }
 
@@ -332,10 +370,11 @@ __global__ __launch_bounds__(BT) void bn_fwd_kernel(const float* __restrict__ a,
                                                     const float* __restrict__ beta, float* __restrict__ rmean,
                                                     float* __restrict__ rvar, float* __restrict__ h,
                                                     float* __restrict__ stats, int B, int C, int HW, float momentum,
-                                                    int groups) {
+                                                    int groups, float* __restrict__ amax) {
     __shared__ double sh[2 * BT / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int q = HW / 4, total = B * q;   // float4 units of one group
+    float am = 0.f;
     const float g = gamma[c], bt = beta[c];
     for (int grp = 0; grp < groups; ++grp) {     // groups are consecutive forward passes: running stats in that order
         const float* ag = a + (int64_t)grp * B * C * HW;
@@ -367,9 +406,14 @@ __global__ __launch_bounds__(BT) void bn_fwd_kernel(const float* __restrict__ a,
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
+            am = amax4(am, o);
             *reinterpret_cast<f32x4*>(hg + off) = o;
         }
         __syncthreads();      // block_sum's scratch is reused by the next group
+    }
+    if (amax) {
+        am = block_amax256(am);
+        if (tid == 0) amax[c] = am;
     }
 }
 
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
                                                     const float* __restrict__ a, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, float* __restrict__ da,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
-                                                    int HW) {
+                                                    int HW, float* __restrict__ amax) {
     __shared__ double sh[2 * BT / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int q = HW / 4, total = B * q;
@@ -404,6 +448,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
         dbeta[c] = (float)red[0];
         dgamma[c] = (float)red[1];
     }
+    float am = 0.f;
     for (int i = tid; i < total; i += BT) {
         const int b = i / q, p = i % q;
         const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
@@ -416,14 +461,19 @@ __global__ __launch_bounds__(BT) void bn_bwd_kernel(const float* __restrict__ dh
             const float dy = lrelu_mask(hv[e]) * dv[e], xh = (av[e] - mu) * r;
             o[e] = g * r * (dy - mb - xh * mg);
         }
+        am = amax4(am, o);
         *reinterpret_cast<f32x4*>(da + off) = o;
+    }
+    if (amax) {
+        am = block_amax256(am);
+        if (tid == 0) amax[c] = am;
     }
 }
 
 // Sliced BatchNorm: SB blocks per channel, each over B / SB samples; same two-launch scheme as GroupNorm.
 // Blocks are (channel, group, slice); a group is one forward pass of B samples, SB slices of B / SB samples each.
 __global__ __launch_bounds__(BT) void bn_fwd_sums(const float* __restrict__ a, double* __restrict__ ws, int B, int C,
-                                                  int HW, int SB, int G) {
+                                                  int HW, int SB, int G, float* __restrict__ amax) {
     __shared__ double sh[2 * BT / 64];
     const int c = blockIdx.x / (SB * G), gs = blockIdx.x % (SB * G), grp = gs / SB, sl = gs % SB, tid = threadIdx.x;
     const int q = HW / 4, bs = B / SB, total = bs * q;
@@ -436,13 +486,14 @@ __global__ __launch_bounds__(BT) void bn_fwd_sums(const float* __restrict__ a, d
     }
     double red[2] = {s, ss};
     block_sum<2>(red, sh);
+    if (amax && gs == 0 && tid == 0) amax[c] = 0.f;      // the apply launch raises it (atomic max: order-free)
     if (tid == 0) { ws[(c * SB * G + gs) * 2] = red[0]; ws[(c * SB * G + gs) * 2 + 1] = red[1]; }
 }
 __global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                                    float* __restrict__ rvar, float* __restrict__ h,
                                                    float* __restrict__ stats, const double* __restrict__ ws, int B, int C,
-                                                   int HW, float momentum, int SB, int world, int G) {
+                                                   int HW, float momentum, int SB, int world, int G, float* __restrict__ amax) {
     const int c = blockIdx.x / (SB * G), gs = blockIdx.x % (SB * G), grp = gs / SB, sl = gs % SB, tid = threadIdx.x;
     const double cnt = (double)B * HW * world;   // world > 1: ws holds the partial sums added over all ranks
     auto group_stats = [&](int gi, double& mu_d, double& var) {
@@ -472,6 +523,7 @@ __global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, 
     }
     const float g = gamma[c], bt = beta[c];
     const int q = HW / 4, bs = B / SB, total = bs * q;
+    float am = 0.f;
     for (int i = tid; i < total; i += BT) {
         const int b = grp * B + sl * bs + i / q, p = i % q;
         const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
@@ -479,12 +531,17 @@ __global__ __launch_bounds__(BT) void bn_fwd_apply(const float* __restrict__ a, 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = lrelu(g * ((v[e] - mu) * r) + bt);
+        am = amax4(am, o);
         *reinterpret_cast<f32x4*>(h + off) = o;
+    }
+    if (amax) {
+        am = block_amax256(am);       // non-negative floats order like their bit patterns
+        if (tid == 0) atomicMax(reinterpret_cast<unsigned int*>(amax) + c, __builtin_bit_cast(unsigned int, am));
     }
 }
 __global__ __launch_bounds__(BT) void bn_bwd_sums(const float* __restrict__ dh, const float* __restrict__ h,
                                                   const float* __restrict__ a, const float* __restrict__ stats,
-                                                  double* __restrict__ ws, int B, int C, int HW, int SB) {
+                                                  double* __restrict__ ws, int B, int C, int HW, int SB, float* __restrict__ amax) {
     __shared__ double sh[2 * BT / 64];
     const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
     const int q = HW / 4, bs = B / SB, total = bs * q;
@@ -505,6 +562,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_sums(const float* __restrict__ dh, 
     }
     double red[2] = {sb, sg};
     block_sum<2>(red, sh);
+    if (amax && sl == 0 && tid == 0) amax[c] = 0.f;
     if (tid == 0) { ws[(c * SB + sl) * 2] = red[0]; ws[(c * SB + sl) * 2 + 1] = red[1]; }
 }
 __global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh, const float* __restrict__ h,
@@ -512,7 +570,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh,
                                                    const float* __restrict__ gamma, float* __restrict__ da,
                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                    const double* __restrict__ ws, int B, int C, int HW, int SB,
-                                                   int world) {
+                                                   int world, float* __restrict__ amax) {
     const int c = blockIdx.x / SB, sl = blockIdx.x % SB, tid = threadIdx.x;
     double t0 = 0.0, t1 = 0.0;
     for (int k = 0; k < SB; ++k) { t0 += ws[(c * SB + k) * 2]; t1 += ws[(c * SB + k) * 2 + 1]; }
@@ -524,6 +582,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh,
     }
     const float mu = stats[c], r = stats[C + c], g = gamma[c];
     const int q = HW / 4, bs = B / SB, total = bs * q;
+    float am = 0.f;
     for (int i = tid; i < total; i += BT) {
         const int b = sl * bs + i / q, p = i % q;
         const int64_t off = ((int64_t)b * C + c) * HW + p * 4;
@@ -536,7 +595,12 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float* __restrict__ dh,
             const float dy = lrelu_mask(hv[e]) * dv[e], xh = (av[e] - mu) * r;
             o[e] = g * r * (dy - mb - xh * mg);
         }
+        am = amax4(am, o);
         *reinterpret_cast<f32x4*>(da + off) = o;
+    }
+    if (amax) {
+        am = block_amax256(am);
+        if (tid == 0) atomicMax(reinterpret_cast<unsigned int*>(amax) + c, __builtin_bit_cast(unsigned int, am));
     }
 }
 
@@ -569,11 +633,11 @@ long long pgan_gn_workspace_bytes(int N) { return (long long)N * SL * 3 * 8; }
 
 // h = lrelu(GroupNorm(1,C)(a)); stats[n] = (mean, rstd).  a, h: [N, C, HW].
 int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
-                long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+                long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
     gn_fwd_sums<<<N * SL, ST, 0, st>>>(a, w, C * HW, C);
-    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C);
+    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C, amax);
     return pgan_launch_status();
 }
 
@@ -597,37 +661,37 @@ int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, fl
     }
     if (!gn_shape_ok(N, C, HW, w, (long long)sizeof(double) * GN_STATIC_MAX_N * SL * 3)) return PGAN_EINVAL;
     gn_fwd_sums<<<N * SL, ST, 0, st>>>(a, w, C * HW, C);
-    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C);
+    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C, nullptr);
     return pgan_launch_status();
 }
 int pgan_gn_fwd_static_max_samples(void) { return GN_STATIC_MAX_N; }
 
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
                 float* stats_b, float* pg, float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW,
-                hipStream_t st) {
+                float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
     gn_bwd_sums<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, pg, pb, w, C * HW, HW, C, pld);
-    gn_bwd_apply<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, d, stats_b, w, C * HW, HW, C);
+    gn_bwd_apply<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, d, stats_b, w, C * HW, HW, C, amax);
     return pgan_launch_status();
 }
 
 int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
     gn_jvp_sums<<<N * SL, ST, 0, st>>>(t, a, stats, w, C * HW, C);
-    gn_jvp_apply<<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, w, C * HW, HW, C);
+    gn_jvp_apply<<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, w, C * HW, HW, C, amax);
     return pgan_launch_status();
 }
 
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
                  const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 void* ws, long long ws_bytes, int N, int C, int HW, hipStream_t st) {
+                 void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
     gn_bwd2_sums<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, pg, pb, w, C * HW, HW, C, pld);
-    gn_bwd2_apply<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, w, C * HW, HW, C);
+    gn_bwd2_apply<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, w, C * HW, HW, C, amax);
     return pgan_launch_status();
 }
 
@@ -639,34 +703,36 @@ long long pgan_bn_workspace_bytes(int C) { return (long long)C * 16 * 2 * 8; }
 // normalised with its own batch statistics (stats: [groups][2][C]) and the running statistics are stepped through
 // the passes in order, exactly as `groups` separate calls would.
 int pgan_bn_fwd(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h, float* stats,
-                void* ws, long long ws_bytes, int B, int C, int HW, float momentum, int groups, hipStream_t st) {
+                void* ws, long long ws_bytes, int B, int C, int HW, float momentum, int groups, float* amax,
+                hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4 || groups < 1) return PGAN_EINVAL;
     const int sb = bn_slices(B, C * groups, HW);
     if (sb == 1 && groups == 1) {
-        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, 1);
+        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, 1, amax);
     } else if (sb == 1 && (long long)B * HW * groups < 8192) {
-        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, groups);
+        bn_fwd_kernel<<<C, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, B, C, HW, momentum, groups, amax);
     } else {
         if (!ws || ws_bytes < (long long)C * sb * groups * 16) return PGAN_EINVAL;
         double* w = static_cast<double*>(ws);
-        bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, w, B, C, HW, sb, groups);
+        bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, w, B, C, HW, sb, groups, amax);
         bn_fwd_apply<<<C * sb * groups, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, w, B, C, HW, momentum, sb, 1,
-                                                     groups);
+                                                     groups, amax);
     }
     return pgan_launch_status();
 }
 
 int pgan_bn_bwd(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, hipStream_t st) {
+                float* dgamma, float* dbeta, void* ws, long long ws_bytes, int B, int C, int HW, float* amax,
+                hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4) return PGAN_EINVAL;
     const int sb = bn_slices(B, C, HW);
     if (sb == 1) {
-        bn_bwd_kernel<<<C, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, B, C, HW);
+        bn_bwd_kernel<<<C, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, B, C, HW, amax);
     } else {
         if (!ws || ws_bytes < pgan_bn_workspace_bytes(C)) return PGAN_EINVAL;
         double* w = static_cast<double*>(ws);
-        bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, w, B, C, HW, sb);
-        bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, w, B, C, HW, sb, 1);
+        bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, w, B, C, HW, sb, amax);
+        bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, w, B, C, HW, sb, 1, amax);
     }
     return pgan_launch_status();
 }
@@ -680,36 +746,37 @@ long long pgan_bn_fwd_partials(int B, int C, int HW, int groups) {
     return groups < 1 ? -1 : (long long)C * bn_slices(B, C * groups, HW) * groups * 2;
 }
 
-int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, hipStream_t st) {
+int pgan_bn_fwd_sums(const float* a, double* part, int B, int C, int HW, int groups, float* amax, hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4 || !part || groups < 1) return PGAN_EINVAL;
     const int sb = bn_slices(B, C * groups, HW);
-    bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, part, B, C, HW, sb, groups);
+    bn_fwd_sums<<<C * sb * groups, BT, 0, st>>>(a, part, B, C, HW, sb, groups, amax);
     return pgan_launch_status();
 }
 
 int pgan_bn_fwd_apply(const float* a, const float* gamma, const float* beta, float* rmean, float* rvar, float* h,
                       float* stats, const double* part, int B, int C, int HW, int world, float momentum, int groups,
-                      hipStream_t st) {
+                      float* amax, hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1 || groups < 1) return PGAN_EINVAL;
     const int sb = bn_slices(B, C * groups, HW);
     bn_fwd_apply<<<C * sb * groups, BT, 0, st>>>(a, gamma, beta, rmean, rvar, h, stats, part, B, C, HW, momentum, sb, world,
-                                                 groups);
+                                                 groups, amax);
     return pgan_launch_status();
 }
 
 int pgan_bn_bwd_sums(const float* dh, const float* h, const float* a, const float* stats, double* part, int B, int C,
-                     int HW, hipStream_t st) {
+                     int HW, float* amax, hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4 || !part) return PGAN_EINVAL;
     const int sb = bn_slices(B, C, HW);
-    bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, part, B, C, HW, sb);
+    bn_bwd_sums<<<C * sb, BT, 0, st>>>(dh, h, a, stats, part, B, C, HW, sb, amax);
     return pgan_launch_status();
 }
 
 int pgan_bn_bwd_apply(const float* dh, const float* h, const float* a, const float* stats, const float* gamma, float* da,
-                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, hipStream_t st) {
+                      float* dgamma, float* dbeta, const double* part, int B, int C, int HW, int world, float* amax,
+                      hipStream_t st) {
     if (B <= 0 || C <= 0 || HW % 4 || !part || world < 1) return PGAN_EINVAL;
     const int sb = bn_slices(B, C, HW);
-    bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, part, B, C, HW, sb, world);
+    bn_bwd_apply<<<C * sb, BT, 0, st>>>(dh, h, a, stats, gamma, da, dgamma, dbeta, part, B, C, HW, sb, world, amax);
     return pgan_launch_status();
 }
 

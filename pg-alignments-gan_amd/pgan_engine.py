@@ -293,6 +293,10 @@ class Engine:
         self.dH[0] = self.X0
         self.dU = stage(NT)
         self.dJ = stage(NT)
+        # largest magnitudes (8 per sample, written by the GroupNorm ops) of the activations dH[k] and the adjoints
+        # dJ[k]: the scaling bounds of the convolutions that read them
+        self.dHmax = [None] + [torch.zeros(NT, 8, **f) for _ in range(nS)]
+        self.dJmax = [None] + [torch.zeros(NT, 8, **f) for _ in range(nS)]
         self.dStat = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]    # mu, rstd
         self.dStatB = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]   # mean(w), mean(w xhat)
         self.dStatT = [None] + [torch.zeros(NT, 2, **f) for _ in range(nS)]   # mean(t), mean(xhat t)
@@ -332,6 +336,9 @@ class Engine:
         self.gA, self.gH = g2(), g2()                    # conv outputs; after BN+LReLU
         self.gStat = [None] + [torch.zeros(2, g2c[i], **f) for i in range(1, nG + 1)]
         self.gdH, self.gdA = g2(), g2()
+        # per-channel largest magnitudes of gH[i] / gdA[i] (written by the BatchNorm ops), bounds for the convolutions
+        self.gHmax = [None] + [torch.zeros(g2c[i], **f) for i in range(1, nG + 1)]
+        self.gdAmax = [None] + [torch.zeros(g2c[i], **f) for i in range(1, nG + 1)]
         self.gXs = torch.zeros(B, 1, S, S, **f)          # generator-step output (sites)
         self.gXp = torch.zeros(B, 1, S, **f)
         self.gdX = torch.zeros(B, 1, S, S, **f)
@@ -432,16 +439,16 @@ class Engine:
             self._bn_parts[key] = part
         return part
 
-    def _bn_fwd(self, key, a, gamma, beta, rmean, rvar, h, stats, groups: int = 1) -> None:
+    def _bn_fwd(self, key, a, gamma, beta, rmean, rvar, h, stats, groups: int = 1, amax=None) -> None:
         """BatchNorm + LeakyReLU forward; with bn_sync set, over the global batch of all ranks (the partial sums of
         every layer go through bn_sync, which adds them over the ranks on the current stream).  groups > 1: a holds
         that many forward passes, each with its own statistics."""
         o = self.ops
         if self.bn_sync is None:
             if groups == 1:
-                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats)
+                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats, amax=amax)
             else:
-                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats, groups=groups)
+                o.bn_fwd(a, gamma, beta, rmean, rvar, h, stats, groups=groups, amax=amax)
             return
         part = self._bn_parts.get(("f", key, groups))
         if part is None:
@@ -449,23 +456,23 @@ class Engine:
             n = o.bn_fwd_partials(a.shape[0] // groups, a.shape[1], hw, groups)
             part = self._bn_parts[("f", key, groups)] = torch.zeros(n, dtype=torch.float64, device=a.device)
         if groups == 1:
-            o.bn_fwd_sums(a, part)
+            o.bn_fwd_sums(a, part, amax=amax)
             self.bn_sync(part)
-            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world)
+            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world, amax=amax)
         else:
-            o.bn_fwd_sums(a, part, groups=groups)
+            o.bn_fwd_sums(a, part, groups=groups, amax=amax)
             self.bn_sync(part)
-            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world, groups=groups)
+            o.bn_fwd_apply(a, gamma, beta, rmean, rvar, h, stats, part, self.bn_world, groups=groups, amax=amax)
 
-    def _bn_bwd(self, key, dh, h, a, stats, gamma, da, dgamma, dbeta) -> None:
+    def _bn_bwd(self, key, dh, h, a, stats, gamma, da, dgamma, dbeta, amax=None) -> None:
         o = self.ops
         if self.bn_sync is None:
-            o.bn_bwd(dh, h, a, stats, gamma, da, dgamma, dbeta)
+            o.bn_bwd(dh, h, a, stats, gamma, da, dgamma, dbeta, amax=amax)
             return
         part = self._bn_part(("b", key), a)
-        o.bn_bwd_sums(dh, h, a, stats, part)
+        o.bn_bwd_sums(dh, h, a, stats, part, amax=amax)
         self.bn_sync(part)
-        o.bn_bwd_apply(dh, h, a, stats, gamma, da, dgamma, dbeta, part, self.bn_world)
+        o.bn_bwd_apply(dh, h, a, stats, gamma, da, dgamma, dbeta, part, self.bn_world, amax=amax)
 
     def _gen_forward_2d(self, out_s: torch.Tensor, bufs=None, groups: int = 1) -> None:
         """2-D tower on (Z, conv outputs, activations, statistics) = bufs (default: the single-pass workspace);
@@ -475,11 +482,12 @@ class Engine:
         o.gemm_nn(Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), gA[1].view(Z.shape[0], -1))
         for i in range(1, self.nG + 1):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
+            # gHmax[i] always describes the forward made last, whose final pass is what the backward reads
             self._bn_fwd(n, gA[i], G[n + ".weight"], G[n + ".bias"], Gb[n + ".running_mean"],
-                         Gb[n + ".running_var"], gH[i], gStat[i], groups)
+                         Gb[n + ".running_var"], gH[i], gStat[i], groups, amax=self.gHmax[i])
             w = G[f"twod_conv_layers.{3 * i}.weight"]
             if i < self.nG:
-                o.conv_up(gH[i], w, gA[i + 1])
+                o.conv_up(gH[i], w, gA[i + 1], bound=self.gHmax[i])
             else:
                 o.conv_up(gH[i], w, out_s, self.act_id)
 
@@ -545,19 +553,20 @@ class Engine:
     def _gen_backward_2d(self, xs, dxs) -> None:
         o, G, dG = self.ops, self.G.p, self.G.g
         o.act_bwd(dxs, xs, self.gdX, self.act_id)
-        up = self.gdX
+        up, up_max = self.gdX, None           # the single-channel top stage takes no bound
         for i in range(self.nG, 0, -1):
             w = G[f"twod_conv_layers.{3 * i}.weight"]
             self.wside.fork()
             with self.wside:      # the weight gradient beside the input-gradient chain
-                o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"])
+                o.conv_wgrad(self.gH[i], up, dG[f"twod_conv_layers.{3 * i}.weight"], bound_s=self.gHmax[i],
+                             bound_l=up_max)
                 if self.gen_grad_ready is not None:
                     self.gen_grad_ready(f"twod_conv_layers.{3 * i}.weight")
-            o.conv_down(up, w, self.gdH[i])
+            o.conv_down(up, w, self.gdH[i], bound=up_max)
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
             self._bn_bwd(n, self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
-                         dG[n + ".weight"], dG[n + ".bias"])
-            up = self.gdA[i]
+                         dG[n + ".weight"], dG[n + ".bias"], amax=self.gdAmax[i])
+            up, up_max = self.gdA[i], self.gdAmax[i]
         o.gemm_tn(self.Z, self.gdA[1].view(self.B, -1), dG["twod_conv_layers.0.weight"].view(self.latent, -1))
         self.wside.join()
 
@@ -578,12 +587,16 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # discriminator pieces
     # ------------------------------------------------------------------------------------------
+    def _hmax(self, k: int, lo: int, hi: int):
+        """Bounds of dH[k][lo:hi] for the convolutions (stage 0 is the input image: single-channel kernels, no bound)."""
+        return self.dHmax[k][lo:hi] if k >= 1 else None
+
     def _d_forward2d(self, lo: int, hi: int) -> None:
         o = self.ops
         for k in range(1, self.nS + 1):
-            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi])
+            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi], bound=self._hmax(k - 1, lo, hi))
             gw, gb = self.dgn(k)
-            o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi])
+            o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi], amax=self.dHmax[k][lo:hi])
 
     def _d_backward1(self, lo: int, hi: int, g_lo: int, g_hi: int, g_out: Optional[torch.Tensor]) -> None:
         """First-order backward of sum_n coef[n] * score[n] through the 2-D tower for slots [lo, hi).
@@ -593,9 +606,10 @@ class Engine:
         for k in range(self.nS, 0, -1):
             gw, _ = self.dgn(k)
             o.gn_bwd(self.dU[k][lo:hi], self.dH[k][lo:hi], self.dA[k][lo:hi], self.dStat[k][lo:hi], gw,
-                     self.dJ[k][lo:hi], self.dStatB[k][lo:hi], self.dPG[k][lo:hi], self.dPB[k][lo:hi])
+                     self.dJ[k][lo:hi], self.dStatB[k][lo:hi], self.dPG[k][lo:hi], self.dPB[k][lo:hi],
+                     amax=self.dJmax[k][lo:hi])
             if k > 1:
-                o.conv_up(self.dJ[k][lo:hi], self.dconv_w(k), self.dU[k - 1][lo:hi])
+                o.conv_up(self.dJ[k][lo:hi], self.dconv_w(k), self.dU[k - 1][lo:hi], bound=self.dJmax[k][lo:hi])
             elif g_out is not None:
                 o.conv_up(self.dJ[1][g_lo:g_hi], self.dconv_w(1), g_out)
 
@@ -624,7 +638,8 @@ class Engine:
         wt = Dp["out.weight"].view(-1)[FEAT2:]
         if want_params:
             for k in range(1, self.nS + 1):
-                o.conv_wgrad(self.dJ[k][:n], self.dH[k - 1][:n], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
+                o.conv_wgrad(self.dJ[k][:n], self.dH[k - 1][:n], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"],
+                             bound_s=self.dJmax[k][:n], bound_l=self._hmax(k - 1, 0, n))
             self._reduce_norm_grads(0, n, 0, 0)
             o.head_wgrad(self.dH[self.nS][:n], coef, Dg["out.weight"].view(-1)[:FEAT2])
             o.head_wgrad(self.F1[:n], coef, Dg["out.weight"].view(-1)[FEAT2:])
@@ -702,7 +717,8 @@ class Engine:
                 o.head_fwd(self.dH[nS][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
                 self._d_backward1(0, 2 * B, 0, 0, None)
                 for k in (range(nS, 0, -1) if self.split_wgrad else ()):
-                    o.conv_wgrad(self.dJ[k][:2 * B], self.dH[k - 1][:2 * B], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"])
+                    o.conv_wgrad(self.dJ[k][:2 * B], self.dH[k - 1][:2 * B], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"],
+                                 bound_s=self.dJmax[k][:2 * B], bound_l=self._hmax(k - 1, 0, 2 * B))
             o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
             self._d_forward2d(2 * B, NS)
             self._d_backward1(2 * B, NS, NS - NP, NS, self.G0[:NP])
@@ -723,10 +739,10 @@ class Engine:
         # tangent forward of v through the 2-D tower (primal state = the penalised samples' slots)
         pl, ph = NS - NP, NS
         for k in range(1, nS + 1):
-            o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT])
+            o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT], bound=self._hmax(k - 1, NS, NT))
             gw_k, _ = self.dgn(k)
             o.gn_jvp(self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph], self.dStat[k][pl:ph], gw_k,
-                     self.dH[k][NS:NT], self.dStatT[k][NS:NT])
+                     self.dH[k][NS:NT], self.dStatT[k][NS:NT], amax=self.dHmax[k][NS:NT])
         # second-order backward of the penalised samples
         hbar = None
         if self.loss == "div":
@@ -736,20 +752,22 @@ class Engine:
             gw_k, _ = self.dgn(k)
             o.gn_bwd2(hbar, self.dU[k][pl:ph], self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph],
                       self.dStat[k][pl:ph], self.dStatB[k][pl:ph], self.dStatT[k][NS:NT], gw_k,
-                      self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT])
+                      self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT], amax=self.dJmax[k][NS:NT])
             # stage k's adjoints are complete over all 4B slots: its weight-gradient pass (one per stage,
             # over all slots) runs on its own stream beside the rest of the chain
             self.wside.fork()
             with self.wside:
                 dw = Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"]
                 if two_chains and self.split_wgrad:
-                    o.conv_wgrad(self.dJ[k][2 * B:], self.dH[k - 1][2 * B:], dw, 0, NP, accumulate=True)
+                    o.conv_wgrad(self.dJ[k][2 * B:], self.dH[k - 1][2 * B:], dw, 0, NP, accumulate=True,
+                                 bound_s=self.dJmax[k][2 * B:], bound_l=self._hmax(k - 1, 2 * B, NT))
                 else:
-                    o.conv_wgrad(self.dJ[k], self.dH[k - 1], dw, NS - NP, NP)
+                    o.conv_wgrad(self.dJ[k], self.dH[k - 1], dw, NS - NP, NP, bound_s=self.dJmax[k],
+                                 bound_l=self._hmax(k - 1, 0, NT))
                 if self.grad_ready is not None:
                     self.grad_ready(f"twod_conv_layers.{3 * (k - 1)}.weight")
             if k > 1:
-                o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT])
+                o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT], bound=self.dJmax[k][NS:NT])
                 hbar = self.dU[k - 1][NS:NT]
         self.wside.join()
         if two_chains and hasattr(o, "release_weights"):

@@ -37,25 +37,25 @@ _SIGS = {
     "pgan_conv_up": [P, P, P, I, I, I, I, I, P],
     "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, I, P],
     "pgan_conv_x3_prep": [P, P, I, I, P],
-    "pgan_conv_down_x3": [P, P, P, I, I, I, I, P],
-    "pgan_conv_up_x3": [P, P, P, I, I, I, I, P],
-    "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P],
+    "pgan_conv_down_x3": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_up_x3": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_conv_h2_prep": [P, P, I, I, P],
-    "pgan_conv_down_h2": [P, P, P, I, I, I, I, P],
-    "pgan_conv_up_h2": [P, P, P, I, I, I, I, P],
-    "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P],
+    "pgan_conv_down_h2": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_up_h2": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
-    "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P],
-    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
+    "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P, P],
+    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
-    "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P],
-    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P],
-    "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, I, P],
-    "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
-    "pgan_bn_fwd_sums": [P, P, I, I, I, I, P],
-    "pgan_bn_fwd_apply": [P, P, P, P, P, P, P, P, I, I, I, I, F, I, P],
-    "pgan_bn_bwd_sums": [P, P, P, P, P, I, I, I, P],
-    "pgan_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P, P],
+    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
+    "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, I, P, P],
+    "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P, P],
+    "pgan_bn_fwd_sums": [P, P, I, I, I, I, P, P],
+    "pgan_bn_fwd_apply": [P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, P],
+    "pgan_bn_bwd_sums": [P, P, P, P, P, I, I, I, P, P],
+    "pgan_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P],
     "pgan_head_fwd": [P, P, P, P, P, I, I, I, P],
     "pgan_head_seed": [P, P, P, I, I, P],
     "pgan_head_wgrad": [P, P, P, I, I, P],
@@ -168,6 +168,32 @@ def set_x3_option(name: str, value: int) -> None:
     """Tile override of the split-operand convolution kernels (both splits) for tuning runs (0 = size-based choice)."""
     _check(_lib.pgan_x3_set_option(name.encode(), int(value)), f"pgan_x3_set_option({name}, {value})")
     _check(_lib.pgan_h2_set_option(name.encode(), int(value)), f"pgan_h2_set_option({name}, {value})")
+
+
+GN_AMAX_SLOTS = 8      # entries per sample that the GroupNorm ops write into an `amax` tensor ([N, 8])
+
+
+def _bound(t: Optional[torch.Tensor], rows: Optional[int] = None):
+    """(pointer, entries per sample, entries) of a magnitude bound for an fp16-split convolution operand: None, a
+    [N, k] tensor (k bounds per sample, rows aligned with the operand's samples) or a 1-D tensor (every entry bounds
+    the whole operand)."""
+    if t is None:
+        return None, 0, 0
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise PganError("expected a contiguous float32 CUDA tensor as magnitude bound")
+    if t.dim() == 2:
+        if rows is not None and t.shape[0] < rows:
+            raise PganError(f"magnitude bound has {t.shape[0]} rows for {rows} samples")
+        return t.data_ptr(), t.shape[1], t.numel()
+    return t.data_ptr(), 0, t.numel()
+
+
+def _amax_out(t: Optional[torch.Tensor], need: int):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < need:
+        raise PganError(f"expected a contiguous float32 CUDA tensor of at least {need} elements for amax")
+    return t.data_ptr()
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -318,27 +344,32 @@ class HipOps:
         return ent[0].data_ptr()
 
     # ---------------- conv family ----------------
-    def conv_down(self, x, w, y):
+    def conv_down(self, x, w, y, bound=None):
+        """bound: magnitude bounds of x from its producer (see _bound); without them the fp16-split kernel scans x."""
         N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
         Cs, hs = w.shape[0], HL // 2
         assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
         if self.split and Cl > 1:
             fn = _lib.pgan_conv_down_h2 if self.precision == "h2" else _lib.pgan_conv_down_x3
-            _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down (split)")
+            _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
+                   "pgan_conv_down (split)")
             return
         _check(_lib.pgan_conv_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down")
 
-    def conv_up(self, y, w, x, act=0):
+    def conv_up(self, y, w, x, act=0, bound=None):
         N, Cs, hs = y.shape[0], y.shape[1], y.shape[2]
         Cl = w.shape[1]
         assert tuple(x.shape) == (N, Cl, 2 * hs, 2 * hs) and w.shape[0] == Cs
         if self.split and Cl > 1 and act == 0:
             fn = _lib.pgan_conv_up_h2 if self.precision == "h2" else _lib.pgan_conv_up_x3
-            _check(fn(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, _stream()), "pgan_conv_up (split)")
+            _check(fn(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
+                   "pgan_conv_up (split)")
             return
         _check(_lib.pgan_conv_up(_ptr(y), _ptr(w), _ptr(x), N, Cs, Cl, hs, act, _stream()), "pgan_conv_up")
 
-    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False):
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False, bound_s=None, bound_l=None):
+        """bound_s / bound_l: magnitude bounds of ya / x (rows of a per-sample bound of x follow x's own sample order:
+        the kernel applies the same slot swap to them as to x)."""
         N, Cs, hs = ya.shape[0], ya.shape[1], ya.shape[2]
         Cl = x.shape[1]
         if n_keep is None:
@@ -351,7 +382,7 @@ class HipOps:
                 raise PganError(f"conv_wgrad workspace: need {need} floats, have {self.ws.numel()}")
             fn = _lib.pgan_conv_wgrad_h2 if h2 else _lib.pgan_conv_wgrad_x3
             _check(fn(_ptr(ya), _ptr(x), _ptr(dw), _ptr(self.ws), self.ws.numel(), N, Cs, Cl, hs, n_keep, n_swap,
-                      int(accumulate), _stream()), "pgan_conv_wgrad (split)")
+                      int(accumulate), *_bound(bound_s, N), *_bound(bound_l, N), _stream()), "pgan_conv_wgrad (split)")
             return
         need = _lib.pgan_conv_wgrad_workspace_floats(N, Cs, Cl, hs)
         if need < 0 or need > self.ws.numel():
@@ -416,10 +447,12 @@ class HipOps:
     def release_weights(self) -> None:
         self._hold = False
 
-    def gn_fwd(self, a, gamma, beta, h, stats):
+    def gn_fwd(self, a, gamma, beta, h, stats, amax=None):
+        """amax (every GroupNorm op): optional [N, GN_AMAX_SLOTS] output, the largest magnitude of each of the eight
+        slices of every sample of the op's main output -- what conv_* take as `bound`."""
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
-                                _stream()), "pgan_gn_fwd")
+                                _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_fwd")
 
     def gn_fwd_static(self, a, gamma, beta, h, stats):
         """gn_fwd with the partial sums in the library's own fixed array (nothing allocated, no workspace)."""
@@ -427,31 +460,32 @@ class HipOps:
         _check(_lib.pgan_gn_fwd_static(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), N, C, _hw(a), _stream()),
                "pgan_gn_fwd_static")
 
-    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b),
-                                _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a), _stream()),
-               "pgan_gn_bwd")
+                                _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a),
+                                _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd")
 
-    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(hd), _ptr(stats_t),
-                                *self._gnws(), N, C, _hw(a), _stream()), "pgan_gn_jvp")
+                                *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_jvp")
 
-    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
                                  _ptr(stats_t), _ptr(gamma), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
-                                 *self._gnws(), N, C, _hw(a), _stream()), "pgan_gn_bwd2")
+                                 *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd2")
 
     # ---------------- BatchNorm ----------------
-    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1):
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1, amax=None):
         """groups > 1: a holds that many consecutive forward passes (a.shape[0] / groups samples each), stats is
-        [groups, 2, C]."""
+        [groups, 2, C].  amax (every BatchNorm op): optional [C] output, the largest magnitude per channel of the
+        op's main output over all samples (and groups) of the call -- a 1-D `bound` for conv_*."""
         B, C = a.shape[0] // groups, a.shape[1]
         assert B * groups == a.shape[0] and stats.numel() >= groups * 2 * C
         _check(_lib.pgan_bn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
-                                *self._bnws(), B, C, _hw(a), momentum, int(groups), _stream()),
+                                *self._bnws(), B, C, _hw(a), momentum, int(groups), _amax_out(amax, C), _stream()),
                "pgan_bn_fwd")
 
     def bn_fwd_partials(self, B, C, HW, groups=1) -> int:
@@ -467,33 +501,34 @@ class HipOps:
             raise PganError("expected a contiguous float64 CUDA tensor of bn_partials() elements")
         return part.data_ptr()
 
-    def bn_fwd_sums(self, a, part, groups=1):
+    def bn_fwd_sums(self, a, part, groups=1, amax=None):
+        """amax: the tensor the following bn_fwd_apply will fill (this call clears it)."""
         B, C = a.shape[0] // groups, a.shape[1]
         _check(_lib.pgan_bn_fwd_sums(_ptr(a), self._part_ptr(part, self.bn_fwd_partials(B, C, _hw(a), groups)), B, C,
-                                     _hw(a), int(groups), _stream()), "pgan_bn_fwd_sums")
+                                     _hw(a), int(groups), _amax_out(amax, C), _stream()), "pgan_bn_fwd_sums")
 
-    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1):
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1, amax=None):
         B, C = a.shape[0] // groups, a.shape[1]
         _check(_lib.pgan_bn_fwd_apply(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(h), _ptr(stats),
                                       self._part_ptr(part, self.bn_fwd_partials(B, C, _hw(a), groups)), B, C, _hw(a),
-                                      int(world), momentum, int(groups), _stream()), "pgan_bn_fwd_apply")
+                                      int(world), momentum, int(groups), _amax_out(amax, C), _stream()), "pgan_bn_fwd_apply")
 
-    def bn_bwd_sums(self, dh, h, a, stats, part):
+    def bn_bwd_sums(self, dh, h, a, stats, part, amax=None):
         B, C = a.shape[:2]
         _check(_lib.pgan_bn_bwd_sums(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats),
-                                     self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a), _stream()),
-               "pgan_bn_bwd_sums")
+                                     self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a),
+                                     _amax_out(amax, C), _stream()), "pgan_bn_bwd_sums")
 
-    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world):
+    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world, amax=None):
         B, C = a.shape[:2]
         _check(_lib.pgan_bn_bwd_apply(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
                                       _ptr(dbeta), self._part_ptr(part, self.bn_partials(B, C, _hw(a))), B, C, _hw(a),
-                                      int(world), _stream()), "pgan_bn_bwd_apply")
+                                      int(world), _amax_out(amax, C), _stream()), "pgan_bn_bwd_apply")
 
-    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
+    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta, amax=None):
         B, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_bn_bwd(_ptr(dh), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(da), _ptr(dgamma),
-                                _ptr(dbeta), *self._bnws(), B, C, _hw(a), _stream()),
+                                _ptr(dbeta), *self._bnws(), B, C, _hw(a), _amax_out(amax, C), _stream()),
                "pgan_bn_bwd")
 
     # ---------------- head ----------------

@@ -198,6 +198,63 @@ def _extremes(hip, rng, N, Cs, Cl, hs):
         close("conv_wgrad over samples of different magnitude", gotw, wantw)
 
 
+def _channel_amax(t):
+    """[C] largest magnitude per channel over samples and positions -- what the BatchNorm ops report."""
+    return t.abs().amax([d for d in range(t.dim()) if d != 1])
+
+
+def _slice_amax(t, slots=8):
+    """[N, slots] largest magnitudes of the `slots` equal slices of every sample -- what the GroupNorm ops report."""
+    return t.reshape(t.shape[0], slots, -1).abs().amax(2).contiguous()
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
+@pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (33, 11, 11)])
+@pytest.mark.parametrize("form", ["per_sample", "global"])
+def test_fp16_split_with_operand_bounds(hip, Cs, Cl, hs, N, keep, swap, form):
+    """The fp16-split kernels scaled by magnitude bounds from the producer (per sample, as GroupNorm reports them, or
+    per channel over the whole tensor, as BatchNorm does) instead of by their own scan of the operands: same 1e-5
+    bound against fp64; samples of very different magnitude keep their own accuracy with per-sample bounds; bounds
+    that are loose by 2^3 cost nothing."""
+    rng = np.random.default_rng(21)
+    mags = torch.logspace(-5, 5, N).view(N, 1, 1, 1) if form == "per_sample" else torch.ones(N, 1, 1, 1)
+    x, y = rnd(rng, N, Cl, 2 * hs, 2 * hs) * mags, rnd(rng, N, Cs, hs, hs) * mags
+    w = rnd(rng, Cs, Cl, 4, 4, scale=0.05)
+    xg, yg, wg = gpu(x, y, w)
+    if form == "per_sample":
+        bx, by = _slice_amax(xg), _slice_amax(yg) * 8.0
+    else:
+        bx, by = xg.abs().amax((0, 2, 3)).contiguous() * 8.0, yg.abs().amax((0, 2, 3)).contiguous()
+    hip.precision = "h2"
+    try:
+        want = torch.zeros(N, Cs, hs, hs, dtype=torch.float64)
+        REF.conv_down(*d64(x, w), want)
+        got = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+        hip.conv_down(xg, wg, got, bound=bx)
+        wantu = torch.zeros(N, Cl, 2 * hs, 2 * hs, dtype=torch.float64)
+        REF.conv_up(*d64(y, w), wantu)
+        gotu = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=DEV)
+        hip.conv_up(yg, wg, gotu, bound=by)
+        for n in range(N):
+            close(f"conv_down, bounded, sample {n}", got[n], want[n])
+            close(f"conv_up, bounded, sample {n}", gotu[n], wantu[n])
+        xw, yw = (x / mags), (y / mags)
+        wantw = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
+        REF.conv_wgrad(*d64(yw, xw), wantw, keep, swap)
+        gotw = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
+        xwg, ywg = gpu(xw, yw)
+        if form == "per_sample":
+            bs, bl = _slice_amax(ywg), _slice_amax(xwg) * 8.0
+        else:
+            bs, bl = ywg.abs().amax((0, 2, 3)).contiguous(), xwg.abs().amax((0, 2, 3)).contiguous()
+        hip.conv_wgrad(ywg, xwg, gotw, keep, swap, bound_s=bs, bound_l=bl)
+        close("conv_wgrad, bounded", gotw, wantw)
+        hip.conv_wgrad(ywg, xwg, gotw, keep, swap, bound_s=bs)          # one operand bounded, the other scanned
+        close("conv_wgrad, half bounded", gotw, wantw)
+    finally:
+        hip.precision = "x3"
+
+
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N,keep,swap", [(5, 5, 0), (8, 4, 2), (12, 0, 6), (33, 11, 11)])
 @pytest.mark.parametrize("pipe", ["fp32", "bf16", "h2"])
@@ -265,7 +322,9 @@ def test_groupnorm_family(hip, C, hs):
     h_w, st_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
     REF.gn_fwd(*d64(a, gamma, beta), h_w, st_w)
     h_g, st_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
-    hip.gn_fwd(*gpu(a, gamma, beta), h_g, st_g)
+    am = torch.full((N, 8), float("nan"), device=DEV)
+    hip.gn_fwd(*gpu(a, gamma, beta), h_g, st_g, amax=am)
+    assert torch.equal(am, _slice_amax(h_g))          # the reported magnitudes are those of the output, exactly
     close("gn_fwd.h", h_g, h_w)
     close("gn_fwd.stats", st_g, st_w)
     h32 = h_g.cpu()   # masks come from the GPU's own forward output
@@ -275,7 +334,8 @@ def test_groupnorm_family(hip, C, hs):
     REF.gn_bwd(*d64(u, h32, a), st_w, gamma.double(), d_w, sb_w, pg_w, pb_w)
     d_g, sb_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
     pg_g, pb_g = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV)
-    hip.gn_bwd(*gpu(u), h_g, a.to(DEV), st_g, gamma.to(DEV), d_g, sb_g, pg_g, pb_g)
+    hip.gn_bwd(*gpu(u), h_g, a.to(DEV), st_g, gamma.to(DEV), d_g, sb_g, pg_g, pb_g, amax=am)
+    assert torch.equal(am, _slice_amax(d_g))
     close("gn_bwd.d", d_g, d_w)
     close("gn_bwd.pg", pg_g, pg_w)
     close("gn_bwd.pb", pb_g, pb_w)
@@ -283,7 +343,8 @@ def test_groupnorm_family(hip, C, hs):
     hd_w, stt_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
     REF.gn_jvp(*d64(t, h32, a), st_w, gamma.double(), hd_w, stt_w)
     hd_g, stt_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
-    hip.gn_jvp(t.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), hd_g, stt_g)
+    hip.gn_jvp(t.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), hd_g, stt_g, amax=am)
+    assert torch.equal(am, _slice_amax(hd_g))
     close("gn_jvp.hd", hd_g, hd_w)
     # second-order backward, with and without an incoming primal adjoint
     for hb in (hbar, None):
@@ -292,7 +353,8 @@ def test_groupnorm_family(hip, C, hs):
                     pg_w, pb_w)
         p_g = torch.zeros(sh, device=DEV)
         hip.gn_bwd2(None if hb is None else hb.to(DEV), u.to(DEV), t.to(DEV), h_g, a.to(DEV), st_g, sb_g, stt_g,
-                    gamma.to(DEV), p_g, pg_g, pb_g)
+                    gamma.to(DEV), p_g, pg_g, pb_g, amax=am)
+        assert torch.equal(am, _slice_amax(p_g))
         close("gn_bwd2.p", p_g, p_w, rtol=2e-5)
         close("gn_bwd2.pg", pg_g, pg_w, rtol=2e-5)
         if hb is not None:
@@ -341,7 +403,9 @@ def test_batchnorm(hip, shape):
     REF.bn_fwd(*d64(a, gamma, beta), rm_w, rv_w, h_w, st_w)
     h_g, st_g = torch.zeros(shape, device=DEV), torch.zeros(2, C, device=DEV)
     rm_g, rv_g = rm.to(DEV), rv.to(DEV)
-    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g)
+    am = torch.full((C,), float("nan"), device=DEV)
+    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g, amax=am)
+    assert torch.equal(am, _channel_amax(h_g))          # largest output magnitude per channel, exactly
     close("bn_fwd.h", h_g, h_w)
     close("bn_fwd.rmean", rm_g, rm_w)
     close("bn_fwd.rvar", rv_g, rv_w)
@@ -349,7 +413,8 @@ def test_batchnorm(hip, shape):
     dg_w, db_w = torch.zeros(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
     REF.bn_bwd(*d64(dh, h_g.cpu(), a), st_w, gamma.double(), da_w, dg_w, db_w)
     da_g, dg_g, db_g = torch.zeros(shape, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    hip.bn_bwd(dh.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), da_g, dg_g, db_g)
+    hip.bn_bwd(dh.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), da_g, dg_g, db_g, amax=am)
+    assert torch.equal(am, _channel_amax(da_g))
     close("bn_bwd.da", da_g, da_w)
     close("bn_bwd.dgamma", dg_g, dg_w)
     close("bn_bwd.dbeta", db_g, db_w)
@@ -372,7 +437,9 @@ def test_batchnorm_forward_passes_in_one_call(hip, groups, shape):
         REF.bn_fwd(*d64(a[g * B:(g + 1) * B], gamma, beta), rm_w, rv_w, h_w[g * B:(g + 1) * B], st_w[g])
     h_g, st_g = torch.zeros(full, device=DEV), torch.zeros(groups, 2, C, device=DEV)
     rm_g, rv_g = rm.to(DEV), rv.to(DEV)
-    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g, groups=groups)
+    am = torch.full((C,), float("nan"), device=DEV)
+    hip.bn_fwd(*gpu(a, gamma, beta), rm_g, rv_g, h_g, st_g, groups=groups, amax=am)
+    assert torch.equal(am, _channel_amax(h_g))
     close("bn_groups.h", h_g, h_w)
     close("bn_groups.stats", st_g, st_w)
     close("bn_groups.rmean", rm_g, rm_w)
@@ -381,8 +448,10 @@ def test_batchnorm_forward_passes_in_one_call(hip, groups, shape):
     part = torch.zeros(hip.bn_fwd_partials(B, C, hw, groups), dtype=torch.float64, device=DEV)
     h_s, st_s = torch.zeros(full, device=DEV), torch.zeros(groups, 2, C, device=DEV)
     rm_s, rv_s = rm.to(DEV), rv.to(DEV)
-    hip.bn_fwd_sums(a.to(DEV), part, groups=groups)
-    hip.bn_fwd_apply(*gpu(a, gamma, beta), rm_s, rv_s, h_s, st_s, part, 1, groups=groups)
+    am.fill_(float("nan"))
+    hip.bn_fwd_sums(a.to(DEV), part, groups=groups, amax=am)
+    hip.bn_fwd_apply(*gpu(a, gamma, beta), rm_s, rv_s, h_s, st_s, part, 1, groups=groups, amax=am)
+    assert torch.equal(am, _channel_amax(h_s))
     close("bn_groups.split.h", h_s, h_w)
     close("bn_groups.split.rmean", rm_s, rm_w)
     close("bn_groups.split.rvar", rv_s, rv_w)
@@ -423,14 +492,16 @@ def test_batchnorm_over_two_ranks(hip, shape):
     da_w = torch.zeros(shape, dtype=torch.float64)
     dg_w, db_w = torch.zeros(C, dtype=torch.float64), torch.zeros(C, dtype=torch.float64)
     REF.bn_bwd(*d64(dh, h_g.cpu(), a), st_w, gamma.double(), da_w, dg_w, db_w)
-    for sl, part in zip(halves, parts):
-        hip.bn_bwd_sums(dhg[sl], h_g[sl], ag[sl], stats[0], part)
+    ams = [torch.full((C,), float("nan"), device=DEV) for _ in halves]
+    for sl, part, am in zip(halves, parts, ams):
+        hip.bn_bwd_sums(dhg[sl], h_g[sl], ag[sl], stats[0], part, amax=am)
     total = parts[0] + parts[1]
     da_g = torch.zeros(shape, device=DEV)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    for sl in halves:
+    for sl, am in zip(halves, ams):
         dg_g, db_g = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-        hip.bn_bwd_apply(dhg[sl], h_g[sl], ag[sl], stats[0], gamma.to(DEV), da_g[sl], dg_g, db_g, total, 2)
+        hip.bn_bwd_apply(dhg[sl], h_g[sl], ag[sl], stats[0], gamma.to(DEV), da_g[sl], dg_g, db_g, total, 2, amax=am)
+        assert torch.equal(am, _channel_amax(da_g[sl]))
         dg += dg_g
         db += db_g
     close("bn2.da", da_g, da_w)

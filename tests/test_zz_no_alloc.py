@@ -19,7 +19,7 @@ def _call(lib, name, a, gamma, beta, ws=None):
                                     HW, stream)
     else:
         rc = lib.pgan_gn_fwd(a.data_ptr(), gamma.data_ptr(), beta.data_ptr(), h.data_ptr(), st.data_ptr(),
-                             ws.data_ptr(), ws.numel(), N, C, HW, stream)
+                             ws.data_ptr(), ws.numel(), N, C, HW, None, stream)
     assert rc == 0, (name, rc)
     torch.cuda.synchronize()
     return h, st

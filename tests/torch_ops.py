@@ -27,14 +27,26 @@ def _mean(x):
     return x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
 
 
+def _put_slice_amax(amax, out):
+    """GroupNorm ops: amax[n, i] = largest magnitude of the i-th of 8 equal slices of sample n of the op's output."""
+    if amax is not None:
+        amax.copy_(out.reshape(out.shape[0], amax.shape[1], -1).abs().amax(2).to(amax.dtype))
+
+
+def _put_channel_amax(amax, out):
+    """BatchNorm ops: amax[c] = largest magnitude of channel c of the op's output."""
+    if amax is not None:
+        amax.copy_(out.abs().amax([d for d in range(out.dim()) if d != 1]).to(amax.dtype))
+
+
 class TorchOps:
     name = "torch"
 
     # ---------------- conv family: weight w[Cs, Cl, 4(,4)], small side S, large side L ----------
-    def conv_down(self, x, w, y):
+    def conv_down(self, x, w, y, bound=None):        # bound (all conv_*): scaling hint of the fp16-split kernels; unused here
         y.copy_(F.conv2d(x, w, None, stride=2, padding=1))
 
-    def conv_up(self, y, w, x, act=0):
+    def conv_up(self, y, w, x, act=0, bound=None):
         o = F.conv_transpose2d(y, w, None, stride=2, padding=1)
         if act == 1:
             o = torch.sigmoid(o)
@@ -42,7 +54,7 @@ class TorchOps:
             o = torch.tanh(o)
         x.copy_(o)
 
-    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False):
+    def conv_wgrad(self, ya, x, dw, n_keep=None, n_swap=0, accumulate=False, bound_s=None, bound_l=None):
         """dw[cs,cl,kh,kw] = sum_n sum_{oh,ow} ya[n,cs,oh,ow] * x[r(n),cl,2oh-1+kh,2ow-1+kw] where
         r(n) = n for n < n_keep, n + n_swap for n_keep <= n < n_keep + n_swap, n - n_swap after."""
         n = ya.shape[0]
@@ -56,7 +68,7 @@ class TorchOps:
         dw.copy_(dw + g if accumulate else g)
 
     # ---------------- GroupNorm(1, C) + LeakyReLU family (per-sample statistics) ----------------
-    def gn_fwd(self, a, gamma, beta, h, stats):
+    def gn_fwd(self, a, gamma, beta, h, stats, amax=None):
         mu = _mean(a)
         var = _mean((a - mu) ** 2)
         r = torch.rsqrt(var + EPS)
@@ -65,33 +77,36 @@ class TorchOps:
         h.copy_(F.leaky_relu(g * ((a - mu) * r) + b, SLOPE))
         stats[:, 0] = mu.flatten()
         stats[:, 1] = r.flatten()
+        _put_slice_amax(amax, h)
 
     def _xhat(self, a, stats):
         sh = (-1,) + (1,) * (a.dim() - 1)
         return (a - stats[:, 0].view(sh)) * stats[:, 1].view(sh), stats[:, 1].view(sh)
 
-    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb):
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None):
         xh, r = self._xhat(a, stats)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
         e = _mask(h) * u
         w = g * e
         mw, mwx = _mean(w), _mean(w * xh)
         d.copy_(r * (w - mw - xh * mwx))
+        _put_slice_amax(amax, d)
         stats_b[:, 0] = mw.flatten()
         stats_b[:, 1] = mwx.flatten()
         red = tuple(range(2, a.dim()))
         pg.copy_((e * xh).sum(red))
         pb.copy_(e.sum(red))
 
-    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t):
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None):
         xh, r = self._xhat(a, stats)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
         tb, c = _mean(t), _mean(xh * t)
         hd.copy_(_mask(h) * g * (r * (t - tb - xh * c)))
+        _put_slice_amax(amax, hd)
         stats_t[:, 0] = tb.flatten()
         stats_t[:, 1] = c.flatten()
 
-    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb):
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None):
         xh, r = self._xhat(a, stats)
         sh = (-1,) + (1,) * (a.dim() - 1)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
@@ -107,6 +122,7 @@ class TorchOps:
         mwxd = r * (mwt - mw * tb - mwx * c)
         Q = q - r * (c * w + mwx * t)
         p.copy_(r * (Q - mQ - xh * (mQx + mwxd)))
+        _put_slice_amax(amax, p)
         xd = r * (t - tb - xh * c)
         red = tuple(range(2, a.dim()))
         pg.copy_((m * u * xd + m * hb * xh).sum(red))
@@ -197,7 +213,7 @@ class TorchOps:
         """c[M,N] = a[K,M]^T @ b[K,N]."""
         c.copy_(a.t() @ b)
 
-    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1):
+    def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1, amax=None):
         """Training-mode BatchNorm + LeakyReLU.  stats[0,c]=batch mean, stats[1,c]=rstd.  Running
         stats are updated in place (momentum, unbiased variance).  groups > 1: that many consecutive forward passes
         stacked along the batch axis, each with its own statistics (stats [groups, 2, C])."""
@@ -206,6 +222,7 @@ class TorchOps:
             for g in range(groups):
                 self.bn_fwd(a[g * B:(g + 1) * B], gamma, beta, rmean, rvar, h[g * B:(g + 1) * B],
                             stats.view(groups, 2, -1)[g], momentum)
+            _put_channel_amax(amax, h)
             return
         red = (0,) + tuple(range(2, a.dim()))
         sh = (1, -1) + (1,) * (a.dim() - 2)
@@ -218,6 +235,7 @@ class TorchOps:
         stats[1] = r
         rmean.mul_(1 - momentum).add_(momentum * mu)
         rvar.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
+        _put_channel_amax(amax, h)
 
     # split form for batch statistics over several ranks: part[c] = (sum, sum of squares) resp. (sum dy, sum dy xhat)
     def bn_partials(self, B, C, HW) -> int:
@@ -226,7 +244,7 @@ class TorchOps:
     def bn_fwd_partials(self, B, C, HW, groups=1) -> int:
         return 2 * C * groups
 
-    def bn_fwd_sums(self, a, part, groups=1):
+    def bn_fwd_sums(self, a, part, groups=1, amax=None):
         if groups > 1:
             B = a.shape[0] // groups
             for g in range(groups):
@@ -237,12 +255,13 @@ class TorchOps:
         part.view(-1, 2)[:, 0] = ad.sum(red)
         part.view(-1, 2)[:, 1] = (ad * ad).sum(red)
 
-    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1):
+    def bn_fwd_apply(self, a, gamma, beta, rmean, rvar, h, stats, part, world, momentum=0.1, groups=1, amax=None):
         if groups > 1:
             B = a.shape[0] // groups
             for g in range(groups):
                 self.bn_fwd_apply(a[g * B:(g + 1) * B], gamma, beta, rmean, rvar, h[g * B:(g + 1) * B],
                                   stats.view(groups, 2, -1)[g], part.view(groups, -1)[g], world, momentum)
+            _put_channel_amax(amax, h)
             return
         sh = (1, -1) + (1,) * (a.dim() - 2)
         n = world * a.numel() // a.shape[1]
@@ -255,8 +274,9 @@ class TorchOps:
         stats[1] = r
         rmean.mul_(1 - momentum).add_(momentum * mu32)
         rvar.mul_(1 - momentum).add_(momentum * (var * (n / max(n - 1, 1))).float())
+        _put_channel_amax(amax, h)
 
-    def bn_bwd_sums(self, dh, h, a, stats, part):
+    def bn_bwd_sums(self, dh, h, a, stats, part, amax=None):
         red = (0,) + tuple(range(2, a.dim()))
         sh = (1, -1) + (1,) * (a.dim() - 2)
         xh = (a - stats[0].view(sh)) * stats[1].view(sh)
@@ -264,7 +284,7 @@ class TorchOps:
         part.view(-1, 2)[:, 0] = dy.double().sum(red)
         part.view(-1, 2)[:, 1] = (dy * xh).double().sum(red)
 
-    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world):
+    def bn_bwd_apply(self, dh, h, a, stats, gamma, da, dgamma, dbeta, part, world, amax=None):
         sh = (1, -1) + (1,) * (a.dim() - 2)
         n = world * a.numel() // a.shape[1]
         xh = (a - stats[0].view(sh)) * stats[1].view(sh)
@@ -273,8 +293,9 @@ class TorchOps:
         dgamma.copy_((sg / world).float())
         dbeta.copy_((sb / world).float())
         da.copy_(gamma.view(sh) * stats[1].view(sh) * (dy - (sb / n).float().view(sh) - xh * (sg / n).float().view(sh)))
+        _put_channel_amax(amax, da)
 
-    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta):
+    def bn_bwd(self, dh, h, a, stats, gamma, da, dgamma, dbeta, amax=None):
         red = (0,) + tuple(range(2, a.dim()))
         sh = (1, -1) + (1,) * (a.dim() - 2)
         n = a.numel() // a.shape[1]
@@ -285,6 +306,7 @@ class TorchOps:
         dgamma.copy_(sg)
         dbeta.copy_(sb)
         da.copy_(gamma.view(sh) * stats[1].view(sh) * (dy - sb.view(sh) / n - xh * sg.view(sh) / n))
+        _put_channel_amax(amax, da)
 
     def act_bwd(self, dy, y, dx, act):
         """dx = dy * act'(pre) expressed through the activation's output y (1 sigmoid, 2 tanh)."""
