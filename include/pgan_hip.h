@@ -59,6 +59,9 @@ int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r
  *   (src/layers.py:441-463 Conv2d, :97-112 ConvTranspose2d; Cl >= 32, no fused activation). */
 long long pgan_conv_x3_prep_bytes(int Cs, int Cl);
 int pgan_conv_x3_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
+/* the same for n <= 6 weight tensors (host arrays of n pointers / sizes) in one launch: a network's stages together */
+int pgan_conv_x3_prep_multi(const float* const* W, void* const* planes, const int* Cs, const int* Cl, int n,
+                            hipStream_t st);
 /* amax, amax_per_sample, amax_count: optional magnitude bounds of the activation operand, used only by the fp16 split
  * below (this split ignores them; pass NULL, 0, 0). */
 int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
@@ -97,6 +100,8 @@ int pgan_x3_set_option(const char* name, int value);
  * L follow L's own sample order (the call applies r(n) to them). */
 long long pgan_conv_h2_prep_bytes(int Cs, int Cl);
 int pgan_conv_h2_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
+int pgan_conv_h2_prep_multi(const float* const* W, void* const* planes, const int* Cs, const int* Cl, int n,
+                            hipStream_t st);      /* n <= 6 tensors in two launches */
 int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
                       int amax_per_sample, int amax_count, hipStream_t st);
 int pgan_conv_up_h2(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,

@@ -48,6 +48,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define FN_PREP_BYTES pgan_conv_h2_prep_bytes
 #define FN_PREP pgan_conv_h2_prep
+#define FN_PREP_MULTI pgan_conv_h2_prep_multi
 #define FN_SET_OPTION pgan_h2_set_option
 #define FN_DOWN pgan_conv_down_h2
 #define FN_UP pgan_conv_up_h2
@@ -58,6 +59,7 @@ constexpr int NPL = 3;
 constexpr bool F16 = false;
 #define FN_PREP_BYTES pgan_conv_x3_prep_bytes
 #define FN_PREP pgan_conv_x3_prep
+#define FN_PREP_MULTI pgan_conv_x3_prep_multi
 #define FN_SET_OPTION pgan_x3_set_option
 #define FN_DOWN pgan_conv_down_x3
 #define FN_UP pgan_conv_up_x3
@@ -165,15 +167,35 @@ __device__ __forceinline__ float bound_max(const Bound& b, int n_lo, int n_hi, F
     }
     return m;
 }
-__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ W, uint32_t* __restrict__ hdr, int64_t n4) {
+// blk of nblk blocks over the n4 float4 of W
+__device__ __forceinline__ void weight_amax_body(const float* __restrict__ W, uint32_t* __restrict__ hdr, int64_t n4, int blk,
+                                                 int nblk) {
     __shared__ float sh[4];
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < n4; i += (int64_t)nblk * 256) {
         const f32x4 v = reinterpret_cast<const f32x4*>(W)[i];
         m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
     m = block_amax(m, sh);
     if (threadIdx.x == 0) atomicMax(hdr, __builtin_bit_cast(uint32_t, m));       // non-negative floats order like their bits
+}
+__global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restrict__ W, uint32_t* __restrict__ hdr, int64_t n4) {
+    weight_amax_body(W, hdr, n4, blockIdx.x, gridDim.x);
+}
+// Several weight tensors per launch (the stages of one network are prepared together): block ranges [first[t], first[t+1]).
+constexpr int PREP_MAX = 6;
+struct PrepSet {
+    const float* W[PREP_MAX];
+    unsigned char* planes[PREP_MAX];       // start of each prepared-weight buffer (header first in the fp16 split)
+    int Cs[PREP_MAX], Cl[PREP_MAX];
+    int first_amax[PREP_MAX + 1], first_prep[PREP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void weight_amax_multi_kernel(PrepSet ps) {
+    int t = 0;
+    while (t + 1 < ps.n && (int)blockIdx.x >= ps.first_amax[t + 1]) ++t;
+    weight_amax_body(ps.W[t], reinterpret_cast<uint32_t*>(ps.planes[t]), (int64_t)ps.Cs[t] * ps.Cl[t] * 4,
+                     blockIdx.x - ps.first_amax[t], ps.first_amax[t + 1] - ps.first_amax[t]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,10 +204,9 @@ __global__ __launch_bounds__(256) void weight_amax_kernel(const float* __restric
 //                                 the patch is read: tap' = 8(kh>>1) + 4(kw>>1) + 2(kh&1) + (kw&1)
 //   up[p][tap][cs/16][cl][cs%16]  UP:   rows cl, one K step = 16 cs at a fixed tap
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, uint16_t* __restrict__ dn,
-                                                   uint16_t* __restrict__ up, int Cs, int Cl,
-                                                   const uint32_t* __restrict__ whdr) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void prep_body(const float* __restrict__ W, uint16_t* __restrict__ dn, uint16_t* __restrict__ up,
+                                          int Cs, int Cl, const uint32_t* __restrict__ whdr, int blk) {
+    const int idx = blk * 256 + threadIdx.x;
     if (idx >= Cs * Cl) return;
     const float sw = F16 ? pow2f(-scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
     const int cs = idx % Cs, cl = idx / Cs;
@@ -213,6 +234,20 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, 
             up[i * plane + (((size_t)t * (Cs / 16) + cs / 16) * Cl + cl) * 16 + (cs & 15)] =
                 (uint16_t)(pk[i][t >> 1] >> (16 * (t & 1)));
     }
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ W, uint16_t* __restrict__ dn,
+                                                   uint16_t* __restrict__ up, int Cs, int Cl,
+                                                   const uint32_t* __restrict__ whdr) {
+    prep_body(W, dn, up, Cs, Cl, whdr, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void prep_multi_kernel(PrepSet ps) {
+    int t = 0;
+    while (t + 1 < ps.n && (int)blockIdx.x >= ps.first_prep[t + 1]) ++t;
+    unsigned char* base = ps.planes[t];
+    uint16_t* dn = reinterpret_cast<uint16_t*>(base + (F16 ? WHDR_BYTES : 0));
+    prep_body(ps.W[t], dn, dn + (size_t)NPL * ps.Cs[t] * ps.Cl[t] * 16, ps.Cs[t], ps.Cl[t],
+              F16 ? reinterpret_cast<const uint32_t*>(base) : nullptr, blockIdx.x - ps.first_prep[t]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -988,6 +1023,27 @@ int FN_PREP(const float* W, void* planes, int Cs, int Cl, hipStream_t st) {
         weight_amax_kernel<<<(int)((n4 + 1023) / 1024 < 256 ? (n4 + 1023) / 1024 : 256), 256, 0, st>>>(W, hdr, n4);
     }
     prep_kernel<<<(Cs * Cl + 255) / 256, 256, 0, st>>>(W, dn, dn + (size_t)NPL * Cs * Cl * 16, Cs, Cl, hdr);
+    return pgan_launch_status();
+}
+
+// The same for n <= 6 weight tensors in two launches (one in the bf16 split) instead of two per tensor.
+int FN_PREP_MULTI(const float* const* W, void* const* planes, const int* Cs, const int* Cl, int n, hipStream_t st) {
+    if (n <= 0 || n > PREP_MAX || !W || !planes || !Cs || !Cl) return PGAN_EINVAL;
+    PrepSet ps;
+    ps.n = n;
+    ps.first_amax[0] = ps.first_prep[0] = 0;
+    for (int t = 0; t < n; ++t) {
+        if (Cs[t] <= 0 || Cl[t] <= 0 || !W[t] || !planes[t]) return PGAN_EINVAL;
+        ps.W[t] = W[t];
+        ps.planes[t] = static_cast<unsigned char*>(planes[t]);
+        ps.Cs[t] = Cs[t];
+        ps.Cl[t] = Cl[t];
+        const int64_t n4 = (int64_t)Cs[t] * Cl[t] * 4;
+        ps.first_amax[t + 1] = ps.first_amax[t] + (int)((n4 + 1023) / 1024 < 256 ? (n4 + 1023) / 1024 : 256);
+        ps.first_prep[t + 1] = ps.first_prep[t] + (Cs[t] * Cl[t] + 255) / 256;
+    }
+    if (F16) weight_amax_multi_kernel<<<ps.first_amax[n], 256, 0, st>>>(ps);
+    prep_multi_kernel<<<ps.first_prep[n], 256, 0, st>>>(ps);
     return pgan_launch_status();
 }
 

@@ -479,6 +479,8 @@ class Engine:
         groups > 1: that many passes stacked along the batch axis."""
         o, G, Gb = self.ops, self.G.p, self.Gbuf.p
         Z, gA, gH, gStat = bufs if bufs is not None else (self.Z, self.gA, self.gH, self.gStat)
+        if hasattr(o, "prepare_weights"):       # prepared copies of all stages' weights in one go
+            o.prepare_weights([G[f"twod_conv_layers.{3 * i}.weight"] for i in range(1, self.nG + 1)], hold=False)
         o.gemm_nn(Z, G["twod_conv_layers.0.weight"].view(self.latent, -1), gA[1].view(Z.shape[0], -1))
         for i in range(1, self.nG + 1):
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
@@ -815,6 +817,8 @@ class Engine:
         if not forward_done:
             self._gen_forward_2d(self.gXs)
         o.affine(self.gXs, 1.0, 0.0, self.X0[:B])                          # copy
+        if hasattr(o, "prepare_weights"):
+            o.prepare_weights([self.dconv_w(k) for k in range(1, nS + 1)], hold=False)
         self._d_forward2d(0, B)
         self.side.wait_mark()
         o.head_fwd(self.dH[nS][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])

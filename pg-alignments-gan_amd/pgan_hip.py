@@ -41,6 +41,8 @@ _SIGS = {
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P, I, I, P],
     "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_conv_h2_prep": [P, P, I, I, P],
+    "pgan_conv_h2_prep_multi": [P, P, P, P, I, P],
+    "pgan_conv_x3_prep_multi": [P, P, P, P, I, P],
     "pgan_conv_down_h2": [P, P, P, I, I, I, I, P, I, I, P],
     "pgan_conv_up_h2": [P, P, P, I, I, I, I, P, I, I, P],
     "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
@@ -322,7 +324,7 @@ class HipOps:
         """Convolutions run on split operands (prepared weight planes) rather than on the fp32 matrix pipe."""
         return self.precision in ("x3", "h2")
 
-    def _weight_planes(self, w):
+    def _planes_entry(self, w):
         Cs, Cl = w.shape[0], w.shape[1]
         h2 = self.precision == "h2"
         key = (w.data_ptr(), Cs, Cl, h2)
@@ -333,6 +335,15 @@ class HipOps:
             nbytes = (_lib.pgan_conv_h2_prep_bytes if h2 else _lib.pgan_conv_x3_prep_bytes)(Cs, Cl)
             ent = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device), False, False]   # [planes, fresh, reset]
             self._planes[key] = ent
+        return ent
+
+    def _planes_stale(self, w) -> bool:
+        return not (self._planes_entry(w)[1] and (self.static_weights or self._hold))
+
+    def _weight_planes(self, w):
+        Cs, Cl = w.shape[0], w.shape[1]
+        h2 = self.precision == "h2"
+        ent = self._planes_entry(w)
         keep = self.static_weights or self._hold
         if not (ent[1] and keep):
             if h2 and (ent[2] or not keep):      # header word 0: largest |w| prepared so far (see pgan_conv_h2_prep)
@@ -434,15 +445,32 @@ class HipOps:
             ent = self._scratch[key]
         return ent[1].data_ptr(), self._bn_bytes
 
-    def prepare_weights(self, weights) -> None:
+    def prepare_weights(self, weights, hold: bool = True) -> None:
         """Build the prepared copies of these convolution weights now, on the current stream, so that later uses on
         several streams (all ordered after this point) find them ready."""
         if self.split:
             self._hold = False
-            for w in weights:
-                if w.shape[1] > 1:
+            todo = [w for w in weights if w.shape[1] > 1 and self._planes_stale(w)]
+            if len(todo) > 1:         # one launch pair for all of them
+                h2 = self.precision == "h2"
+                ents = [self._planes_entry(w) for w in todo]
+                for ent in ents:
+                    if h2 and (ent[2] or not self.static_weights):
+                        ent[0][:4].zero_()
+                    ent[2] = False
+                n = len(todo)
+                wa = (c_void_p * n)(*[_ptr(w) for w in todo])
+                pa = (c_void_p * n)(*[ent[0].data_ptr() for ent in ents])
+                cs = (c_int * n)(*[w.shape[0] for w in todo])
+                cl = (c_int * n)(*[w.shape[1] for w in todo])
+                fn = _lib.pgan_conv_h2_prep_multi if h2 else _lib.pgan_conv_x3_prep_multi
+                _check(fn(wa, pa, cs, cl, n, _stream()), "pgan_conv_prep_multi")
+                for ent in ents:
+                    ent[1] = True
+            else:
+                for w in todo:
                     self._weight_planes(w)
-            self._hold = True         # until release_weights(): no re-preparation from a second stream
+            self._hold = bool(hold)   # until release_weights(): no re-preparation from a second stream
 
     def release_weights(self) -> None:
         self._hold = False

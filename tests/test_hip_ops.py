@@ -198,6 +198,37 @@ def _extremes(hip, rng, N, Cs, Cl, hs):
         close("conv_wgrad over samples of different magnitude", gotw, wantw)
 
 
+@pytest.mark.parametrize("split", ["x3", "h2"])
+def test_weights_prepared_together(hip, split):
+    """prepare_weights: the prepared planes of several weight tensors built by one launch pair give the same
+    convolution results, bit for bit, as planes built tensor by tensor."""
+    rng = np.random.default_rng(31)
+    N = 3
+    layers = [(128, 64, 16), (256, 128, 8), (512, 256, 4)]
+    xs = [rnd(rng, N, Cl, 2 * hs, 2 * hs).to(DEV) for _, Cl, hs in layers]
+    ws = [rnd(rng, Cs, Cl, 4, 4, scale=0.05 * (i + 1)).to(DEV) for i, (Cs, Cl, _) in enumerate(layers)]
+    hip.precision = split
+    try:
+        hip.invalidate_weight_planes(reset=True)
+        one = []
+        for x, w, (Cs, _, hs) in zip(xs, ws, layers):
+            y = torch.empty(N, Cs, hs, hs, device=DEV)
+            hip.conv_down(x, w, y)
+            one.append(y)
+        hip.invalidate_weight_planes(reset=True)
+        hip.prepare_weights(ws)
+        try:
+            for x, w, (Cs, _, hs), want in zip(xs, ws, layers, one):
+                y = torch.empty(N, Cs, hs, hs, device=DEV)
+                hip.conv_down(x, w, y)
+                assert torch.equal(y, want), (Cs, hs)
+        finally:
+            hip.release_weights()
+    finally:
+        hip.precision = "x3"
+        hip.invalidate_weight_planes(reset=True)
+
+
 def _channel_amax(t):
     """[C] largest magnitude per channel over samples and positions -- what the BatchNorm ops report."""
     return t.abs().amax([d for d in range(t.dim()) if d != 1])
