@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void prep_multi_kernel(PrepSet ps) {
 template <int HS, int BM, int BN, int CLC, int KG>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl,
-                                                           const uint32_t* __restrict__ whdr, Bound bx) {
+                                                           const uint32_t* __restrict__ whdr, Bound bx, int cs_major) {
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -287,7 +287,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
     const int nmt = Cs / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
-    const int ptile = b / nmt, cs0 = (b % nmt) * BM;
+    // Each XCD gets a contiguous run of b.  cs_major: a run is one row tile (its weight planes stay in that XCD's L2)
+    // over all pixel tiles -- for layers whose weight planes outweigh the activations; otherwise a run is a range of
+    // pixel tiles over all row tiles.
+    const int ptile = cs_major ? b % npt : b / nmt, cs0 = (cs_major ? b / npt : b % nmt) * BM;
     int n0, oh0;
     T::origin(ptile, n0, oh0);
 
@@ -916,6 +919,7 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
     return pgan_launch_status();
 }
 
+int g_dn_order = 0;      // tuning override "down_order": 1 pixel-tile-major, 2 row-tile-major block order (0 = by size)
 // ks: 1 | 2 (blocks along K, two-addend sums) | 4 (two blocks of two wave groups each)
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
@@ -924,8 +928,9 @@ int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs
     const int gy = ks > 1 ? 2 : 1;
     if (gy > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), gy);
-    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx);
-    else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx);
+    const int csm = g_dn_order ? g_dn_order - 1 : ((int64_t)Cs * Cl * 16 * NPL * 2 > (int64_t)N * Cl * HS * HS * 16);
+    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
+    else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
     return pgan_launch_status();
 }
 
@@ -944,6 +949,7 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
         int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
         if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
         else if (Cs % 128 == 0 && b4 >= 512 && Cl >= 256) { v = 2; k = 2; }      // long K: 128x64 tiles, K over two blocks
+        else if (Cs % 128 == 0 && b4 >= 256 && b4 < 512 && Cl >= 128) { v = 2; k = 4; }   // ... over two blocks x two wave groups
         while (k > 1 && Cl % (8 * k)) k >>= 1;
         if (variant == 0) variant = v;
         if (ks < 1) ks = k;
@@ -1003,6 +1009,7 @@ int FN_SET_OPTION(const char* name, int value) {
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
     if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_order") && value >= 0 && value <= 2) { g_up_order = value; return PGAN_OK; }
+    if (eq(name, "down_order") && value >= 0 && value <= 2) { g_dn_order = value; return PGAN_OK; }
     if (eq(name, "wg_target") && (value == 0 || (value >= 64 && value <= 4096))) { g_wg_target = value ? value : 512; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;

@@ -53,7 +53,7 @@ for N in [int(v) for v in sys.argv[1:]] or [64, 128, 256]:
         yo, xo, dw = torch.empty_like(y), torch.empty_like(x), torch.empty_like(w)
         print(f"N={N} Cs={Cs} Cl={Cl} hs={hs}")
         sweep("down", lambda: ops.conv_down(x, w, yo), fl,
-              [{}] + [dict(down_variant=v, down_ks=k) for v in (2, 3, 4) for k in (1, 2, 4)])
+              [{}] + [dict(down_order=o) for o in (1, 2)] + [dict(down_variant=v, down_ks=k) for v in (2, 4) for k in (1, 2, 4)])
         sweep("up", lambda: ops.conv_up(y, w, xo), fl,
               [{}] + [dict(up_variant=v, up_ks=k) for v in (1, 2, 3, 5) for k in (1, 2)] +
               [dict(up_variant=5, up_order=o) for o in (1, 2)])
