@@ -229,16 +229,18 @@ class Engine:
         f = dict(dtype=torch.float32, device=device)
 
         # parameter stores may be handed in (the nn.Module front-ends own theirs) or created here
+        # Layout of the flat buffers: the large 2-D convolution weights sit at the end.  Their gradients are complete
+        # early in a backward pass (last stage first) and a data-parallel run reduces each on its own as soon as it
+        # is; everything else is then one contiguous range reduced after the backward.
+        def tail_last(shapes, names):
+            for n in names:
+                shapes[n] = shapes.pop(n)
+            return shapes
         if d_store is None:
-            # the last 2-D stage's weights (3/4 of the discriminator) sit at the end of the flat buffers: their
-            # gradient is complete first in a backward pass and is reduced on its own in data-parallel runs,
-            # the rest then being one contiguous range
-            shapes = disc_param_shapes(self.data)
-            last = f"twod_conv_layers.{3 * (self.nS - 1)}.weight"
-            shapes[last] = shapes.pop(last)
-            d_store = FlatStore(shapes, device)
+            d_store = FlatStore(tail_last(disc_param_shapes(self.data), self.early_d_names(self.nS)), device)
         self.D = d_store
-        self.G = g_store if g_store is not None else FlatStore(gen_param_shapes(latent, self.data), device)
+        self.G = g_store if g_store is not None else FlatStore(
+            tail_last(gen_param_shapes(latent, self.data), self.early_g_names(self.nG)), device)
         if g_buffers is not None:
             self.Gbuf = g_buffers
         else:
@@ -346,6 +348,16 @@ class Engine:
         self.hStat = [None] + [torch.zeros(2, g1c[i], **f) for i in range(1, nG + 1)]
         self.hdH, self.hdA = g1(), g1()
         self.hdX = torch.zeros(B, 1, S, **f)
+
+    @staticmethod
+    def early_d_names(nS: int):
+        """Discriminator gradients worth reducing on their own: the 2-D stages' weights above the single-channel one."""
+        return [f"twod_conv_layers.{3 * (k - 1)}.weight" for k in range(2, nS + 1)]
+
+    @staticmethod
+    def early_g_names(nG: int):
+        """The generator's transposed-convolution weights below the single-channel output layer."""
+        return [f"twod_conv_layers.{3 * i}.weight" for i in range(nG - 1, 0, -1)]
 
     # ------------------------------------------------------------------------------------------
     def _init_coefs(self, wasserstein: bool = True):
