@@ -637,18 +637,19 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 
 // ------------------------------------------------------------------------------------------------
 // WGRAD: dW[cs][cl][kh][kw] = sum over (n, oh, ow) of S[n][cs][oh][ow] * L[r(n)][cl][2oh-1+kh][2ow-1+kw].
-// GEMM M = cs (64 per block), N = (cl, tap) (8 cl x 16 taps per block), K = pixels, 64 per chunk, split
-// over gridDim.y into partial slabs.  Both operands are activations: both are split while they are
-// staged into LDS (single buffer, the next chunk's global loads in flight during the MFMAs).
+// GEMM M = cs (64 or 128 per block), N = (cl, tap) (8 cl x 16 taps per block), K = pixels, 64 per chunk, split
+// over blocks into partial slabs.  Both operands are activations: both are split while they are
+// staged into LDS.  Two LDS images: the MFMAs of a chunk run on one while the next chunk is split into the other
+// between them, and the chunk after that is in flight from global memory (one barrier per chunk).
 // A MFMA K step is 16 consecutive pixels (8 per lane half), so the L side is stored as an im2col along the
 // K direction only: for HS >= 8, per channel four kw-planes P[kw][row][ow] = L[row][2ow-1+kw], whose eight
 // consecutive ow are 16 contiguous bytes; for HS = 4 (eight pixels = two rows) a full im2col [tap][pixel].
-// Plane strides (HS >= 8) and a swap of the two 16-byte pixel halves on odd kh (HS = 4) spread the 16
+// Plane strides (HS >= 8) and a swap of the two 16-byte pixel halves for kh >= 2 (HS = 4) spread the 16
 // (kh, kw) lanes of a channel evenly over the banks.
 // ------------------------------------------------------------------------------------------------
-template <int HS>
+template <int HS, int BM_>
 struct WgGeom {
-    static constexpr int PIXC = 64, BM = 64, CLB = 8;
+    static constexpr int PIXC = 64, BM = BM_, CLB = 8;
     using T = PixTile<HS, PIXC>;
     static constexpr int SEG = T::SEG, R = T::R, WS = HS, HL = 2 * HS, WL = 2 * HS;
     static constexpr int ARS = PIXC * 2 + 16;                        // bytes per A row
@@ -656,115 +657,158 @@ struct WgGeom {
     // HS >= 8: kw planes
     static constexpr int PRR = 2 * R + 2;                            // raw rows per chunk
     static constexpr int SR = WS * 2;                                // bytes per plane row (WS bf16)
-    static constexpr int KWB = PRR * SR + ((PRR * SR / 16) % 2 == 0 && HS >= 16 ? 16 : 0);
-    static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB;        // bytes per (segment,) channel
+    // kw-plane and channel strides chosen (by enumeration over the lane groups of a 16-byte LDS read) so that the 16
+    // (kh, kw) lanes x 2 channels of a fragment read fall on distinct banks
+    static constexpr int KWB = PRR * SR + (HS == 8 ? 32 : (HS == 32 ? 16 : 0));
+    static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB + (HS == 16 ? 16 : (HS == 32 ? 192 : 0));        // bytes per (segment,) channel
     static constexpr int BPL = (HS == 4) ? SEG * CLB * CHB : CLB * CHB;
     static constexpr int LDS_BYTES = NPL * APL + NPL * BPL;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "LDS of one CU");
     // staging items of the L side
     static constexpr int NIB = (HS == 4) ? SEG * CLB * 4 * 4 : CLB * PRR * (WS / 2);
     static constexpr int NQB = (NIB + 255) / 256;
 };
 
-template <int HS>
+// Everything a thread needs per chunk beyond two block-uniform base pointers is fixed before the K loop: byte offsets of
+// its global loads (32-bit, added to the uniform base by the load itself), LDS addresses of its stores, and which of its
+// patch rows fall outside the image at the top / bottom chunk of a sample.
+template <int HS, int BM>
 __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restrict__ YA, const float* __restrict__ X,
                                                             float* __restrict__ slab, int N, int Cs, int Cl, int n_keep,
                                                             int n_swap, int chunks_per_block, Bound bs, Bound bl) {
-    using G = WgGeom<HS>;
+    using G = WgGeom<HS, BM>;
     using T = typename G::T;
-    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, SEG = G::SEG, R = G::R, PIXC = G::PIXC, BM = G::BM, CLB = G::CLB;
-    constexpr int AV = BM * PIXC / 4 / 256;          // f32x4 of the S tile per thread (4)
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, SEG = G::SEG, R = G::R, PIXC = G::PIXC, CLB = G::CLB;
+    constexpr int AV = BM * PIXC / 4 / 256;          // f32x4 of the S tile per thread
+    constexpr int TMW = BM / 64;                     // 32-row tiles per wave
     constexpr int NQB = G::NQB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS_BYTES];
-    unsigned char* As = lds;
-    unsigned char* Bs = lds + NPL * G::APL;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::LDS_BYTES];      // two images of a chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
-    const int nct = Cl / CLB;
-    const int cs0 = (blockIdx.x / nct) * BM, cl0 = (blockIdx.x % nct) * CLB;
+    // Blocks that work on the same pixels (one K range, all the output tiles) read the same S rows and L patches: an
+    // XCD gets a contiguous run of the (K range, tile) list, K range slowest, so those re-reads stay in its L2.
+    const int nct = Cl / CLB, ntile = (Cs / BM) * nct;
+    const int b = xcd_remap(blockIdx.x, gridDim.x), ky = b / ntile, tile = b % ntile;
+    const int cs0 = (tile / nct) * BM, cl0 = (tile % nct) * CLB;
     const int total_chunks = T::ntiles(N);
-    const int c_begin = blockIdx.y * chunks_per_block;
+    const int c_begin = ky * chunks_per_block;
     const int c_end = min(total_chunks, c_begin + chunks_per_block);
+    auto remap = [&](int n) { return n + (n < n_keep ? 0 : (n < n_keep + n_swap ? n_swap : -n_swap)); };
 
     // S tile: item q = (row, 4 pixels)
-    int a_row[AV], a_seg[AV], a_in[AV], a_lds[AV];
+    uint32_t a_off[AV];
+    int a_seg[AV], a_lds[AV];
 #pragma unroll
     for (int q = 0; q < AV; ++q) {
         const int idx = tid + 256 * q, row = idx / (PIXC / 4), p = (idx % (PIXC / 4)) * 4;
-        a_row[q] = row;
         a_seg[q] = p / (R * WS);
-        a_in[q] = p % (R * WS);
+        a_off[q] = 4u * (uint32_t)((a_seg[q] * Cs + cs0 + row) * (HS * HS) + p % (R * WS));
         a_lds[q] = row * G::ARS + p * 2;
     }
     f32x4 areg[AV];
     float sa = 1.f, sb = 1.f;      // fp16 split: scales of the block's S rows and L patches (2^-ea, 2^-eb)
     int ea = 0, eb = 0;
-    // L side items
+    // L side items.  HS = 4: (segment, channel, kh, oh) -> one input row of 8; else (channel, patch row, 4 columns) -> 6 values
     constexpr int NBR = (HS == 4) ? 8 : 6;            // raw floats per item
+    uint32_t b_off[NQB];
+    int b_lds[NQB], b_flag[NQB];      // flags: 1 item exists, 2 first / 4 last patch row, 8 has a left / 16 a right neighbour, 32 (HS = 4) row inside the image
+    const uint32_t xsample = 4u * (uint32_t)(Cl * HL * WL);       // bytes per sample of L
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+        const int e = tid + 256 * q;
+        if constexpr (HS == 4) {
+            const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
+            const int ih = 2 * oh - 1 + kh;
+            b_flag[q] = (e < G::NIB ? 1 : 0) | ((ih >= 0 && ih < HL) ? 32 : 0);
+            b_off[q] = 4u * (uint32_t)(((cl0 + ch) * HL + ((b_flag[q] & 32) ? ih : 0)) * WL);
+            b_lds[q] = ((seg * CLB + ch) * 16 + kh * 4) * 32 + (((oh >> 1) ^ (kh >> 1)) * 2 + (oh & 1)) * 8;
+        } else {
+            constexpr int ND = WS / 2;
+            const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
+            b_flag[q] = (e < G::NIB ? 1 : 0) | (r == 0 ? 2 : 0) | (r == G::PRR - 1 ? 4 : 0) | (d > 0 ? 8 : 0) |
+                        (4 * d + 4 < WL ? 16 : 0);
+            b_off[q] = 4u * (uint32_t)(((cl0 + ch) * HL + r) * WL + 4 * d);       // from row 2 oh0 - 1 of the sample
+            b_lds[q] = ch * G::CHB + r * G::SR + d * 4;
+        }
+    }
     float breg[NQB][NBR];
-    auto gload = [&](int chunk) {
+    // block-uniform part of a chunk's addresses
+    struct Src {
+        const char* ya;
+        const char* xb;
+        int n0, out_mask;
+    };
+    auto src_of = [&](int chunk) {
         int n0, oh0;
         T::origin(chunk, n0, oh0);
-#pragma unroll
-        for (int q = 0; q < AV; ++q) {
-            const int n = n0 + a_seg[q];
+        Src r;
+        r.ya = reinterpret_cast<const char*>(YA) + 4 * ((int64_t)n0 * Cs * (HS * HS) + oh0 * WS);
+        // HS >= 8: rows 2 oh0 - 1 .. of sample r(n0); the base may point one row before the sample, which is never read
+        r.xb = reinterpret_cast<const char*>(X) +
+               (HS == 4 ? (int64_t)0 : (int64_t)remap(n0) * xsample + 4 * (2 * oh0 - 1) * WL);
+        r.n0 = n0;
+        r.out_mask = (oh0 == 0 ? 2 : 0) | (oh0 + R == HS ? 4 : 0);      // patch rows outside the image
+        return r;
+    };
+    constexpr int NST = AV + NQB;         // staging items per thread and chunk: S first, then L
+    auto load_item = [&](auto itc, const Src& sc) {
+        constexpr int it = decltype(itc)::value;
+        if constexpr (it < AV) {
+            constexpr int q = it;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < N)
-                v = *reinterpret_cast<const f32x4*>(YA + (((int64_t)n * Cs + cs0 + a_row[q]) * HS + oh0) * WS + a_in[q]);
+            if (SEG == 1 || sc.n0 + a_seg[q] < N) v = *reinterpret_cast<const f32x4*>(sc.ya + a_off[q]);
             areg[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            const int e = tid + 256 * q;
-            if constexpr (HS == 4) {
-                const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
-                const int n = n0 + seg, ih = 2 * oh - 1 + kh;
-                const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
-                const bool ok = e < G::NIB && n < N && ih >= 0 && ih < HL;
-                const float* src = X + (((int64_t)(ok ? rn : 0) * Cl + cl0 + ch) * HL + (ok ? ih : 0)) * WL;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { breg[q][i] = ok ? v0[i] : 0.f; breg[q][4 + i] = ok ? v1[i] : 0.f; }
-            } else {
-                constexpr int ND = WS / 2;
-                const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
-                const int n = n0, ih = 2 * oh0 - 1 + r;
-                const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
-                const bool ok = e < G::NIB && n < N && ih >= 0 && ih < HL;
-                const float* src = X + (((int64_t)(ok ? rn : 0) * Cl + cl0 + ch) * HL + (ok ? ih : 0)) * WL + 4 * d;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-                breg[q][0] = (ok && d > 0) ? src[-1] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) breg[q][1 + i] = ok ? v[i] : 0.f;
-                breg[q][5] = (ok && 4 * d + 4 < WL) ? src[4] : 0.f;
+        } else if constexpr (HS == 4) {
+            constexpr int q = it - AV;
+            const int n = sc.n0 + (tid + 256 * q) / (CLB * 16);
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if ((b_flag[q] & 33) == 33 && n < N) {
+                const char* src = sc.xb + ((uint32_t)remap(n) * xsample + b_off[q]);
+                v0 = *reinterpret_cast<const f32x4*>(src);
+                v1 = *reinterpret_cast<const f32x4*>(src + 16);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { breg[q][i] = v0[i]; breg[q][4 + i] = v1[i]; }
+        } else {
+            constexpr int q = it - AV;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            float lft = 0.f, rgt = 0.f;
+            if ((b_flag[q] & 1) && !(b_flag[q] & sc.out_mask)) {
+                const char* src = sc.xb + b_off[q];
+                v = *reinterpret_cast<const f32x4*>(src);
+                if (b_flag[q] & 8) lft = *reinterpret_cast<const float*>(src - 4);
+                if (b_flag[q] & 16) rgt = *reinterpret_cast<const float*>(src + 16);
+            }
+            breg[q][0] = lft;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) breg[q][1 + i] = v[i];
+            breg[q][5] = rgt;
         }
     };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < AV; ++q) {
+    // split item `it` of the registers into the LDS image at `img` (A planes, then B planes)
+    auto stage_item = [&](auto itc, unsigned char* img) {
+        constexpr int it = decltype(itc)::value;
+        if constexpr (it < AV) {
+            constexpr int q = it;
             uint32_t pa[NPL], pb[NPL];
             split3(areg[q][0] * sa, areg[q][1] * sa, pa);
             split3(areg[q][2] * sa, areg[q][3] * sa, pb);
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 u32x2 v = {pa[i], pb[i]};
-                *reinterpret_cast<u32x2*>(As + i * G::APL + a_lds[q]) = v;
+                *reinterpret_cast<u32x2*>(img + i * G::APL + a_lds[q]) = v;
             }
-        }
-#pragma unroll
-        for (int q = 0; q < NQB; ++q) {
-            const int e = tid + 256 * q;
-            if (e >= G::NIB) continue;
+        } else {
+            constexpr int q = it - AV;
+            if (!(b_flag[q] & 1)) return;
+            unsigned char* base = img + NPL * G::APL + b_lds[q];
             if constexpr (HS == 4) {
-                const int seg = e / (CLB * 16), ch = (e / 16) % CLB, kh = (e / 4) % 4, oh = e % 4;
                 uint32_t s01[NPL], s23[NPL], s45[NPL], s67[NPL];
                 split3(breg[q][0] * sb, breg[q][1] * sb, s01);
                 split3(breg[q][2] * sb, breg[q][3] * sb, s23);
                 split3(breg[q][4] * sb, breg[q][5] * sb, s45);
                 split3(breg[q][6] * sb, breg[q][7] * sb, s67);
-                unsigned char* base = Bs + ((seg * CLB + ch) * 16 + kh * 4) * 32 + (((oh >> 1) ^ (kh & 1)) * 2 + (oh & 1)) * 8;
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     // values at input columns 2ow-1+kw for ow = 0..3: kw 0: (-,1,3,5)  1: (0,2,4,6)  2: (1,3,5,7)  3: (2,4,6,-)
@@ -779,13 +823,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
                     *reinterpret_cast<u32x2*>(b + 96) = k3;
                 }
             } else {
-                constexpr int ND = WS / 2;
-                const int ch = e / (G::PRR * ND), r = (e / ND) % G::PRR, d = e % ND;
                 uint32_t s01[NPL], s23[NPL], s45[NPL];
                 split3(breg[q][0] * sb, breg[q][1] * sb, s01);
                 split3(breg[q][2] * sb, breg[q][3] * sb, s23);
                 split3(breg[q][4] * sb, breg[q][5] * sb, s45);
-                unsigned char* base = Bs + ch * G::CHB + r * G::SR + d * 4;
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     // plane kw, positions (2d, 2d+1) = input columns (4d-1+kw, 4d+1+kw)
@@ -798,16 +839,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             }
         }
     };
+    auto gload = [&](int chunk) {
+        const Src sc = src_of(chunk);
+        static_for<NST>([&](auto ic) { load_item(ic, sc); });
+    };
 
-    // fragment addresses (bytes): A row of this lane; B column (cl, kh, kw) of this lane per pixel tile
-    const int abase = (wm * 32 + j) * G::ARS + h * 16;
+    // fragment addresses (bytes): A rows of this lane; B column (cl, kh, kw) of this lane per pixel tile
+    int abase[TMW];
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) abase[tm] = (wm * (BM / 2) + tm * 32 + j) * G::ARS + h * 16;
     int bbase[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int cl_l = wn * 4 + tn * 2 + (j >> 4), kh = (j >> 2) & 3, kw = j & 3;
         if constexpr (HS >= 16) bbase[tn] = cl_l * G::CHB + kw * G::KWB + kh * G::SR + h * 16;
         else if constexpr (HS == 8) bbase[tn] = cl_l * G::CHB + kw * G::KWB + (2 * h + kh) * G::SR;
-        else bbase[tn] = (cl_l * 16 + (j & 15)) * 32 + (h ^ (kh & 1)) * 16;
+        else bbase[tn] = (cl_l * 16 + (j & 15)) * 32 + (h ^ (kh >> 1)) * 16;
     }
     // byte offset of the B fragment of K step s (16 consecutive pixels: half a row at HS = 32, one row at 16, two at 8,
     // a whole sample at 4)
@@ -815,11 +862,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         return (HS == 32) ? (s >> 1) * 2 * G::SR + (s & 1) * 32
                           : s * ((HS == 16) ? 2 * G::SR : (HS == 8 ? 4 * G::SR : CLB * G::CHB));
     };
-    f32x16 acc[2], acl[2];
+    f32x16 acc[TMW][2], acl[TMW][2];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[tn][r] = 0.f; acl[tn][r] = 0.f; }
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; acl[tm][tn][r] = 0.f; }
 
     if constexpr (F16) {       // one pass over this block's chunks for the largest magnitude of each operand
         float ma = 0.f, mb = 0.f;
@@ -830,9 +879,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             n_hi = min(n_hi + SEG, N);
         }
         if (bs.p) ma = bound_max(bs, n_lo, n_hi, [](int n) { return n; });
-        if (bl.p) mb = bound_max(bl, n_lo, n_hi, [&](int n) {
-            return (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
-        });
+        if (bl.p) mb = bound_max(bl, n_lo, n_hi, remap);
         if (!bs.p || !bl.p) for (int ch = c_begin; ch < c_end; ++ch) {
             gload(ch);
 #pragma unroll
@@ -849,37 +896,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         sa = pow2f(-ea);
         sb = pow2f(-eb);
     }
-    if (c_begin < c_end) gload(c_begin);
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        lstore();
+    // K loop, one barrier per chunk: the MFMAs of chunk c read LDS image c & 1 while the registers (chunk c + 1) are split
+    // into the other image item by item between them, and every item's registers are refilled from chunk c + 2 as soon as
+    // they are free.  Chunks past the block's range repeat its last one; what they stage is never read.
+    constexpr int KS = PIXC / 16;
+    auto chunk_of = [&](int c) { return min(c, c_end - 1); };
+    auto frags = [&](auto setc, auto sc, const unsigned char* img, u32x4 (&a)[2][TMW][NPL], u32x4 (&bo)[2][2][NPL]) {
+        constexpr int set = decltype(setc)::value, s = decltype(sc)::value;
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(img + i * G::APL + abase[tm] + s * 32);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                bo[set][tn][i] = *reinterpret_cast<const u32x4*>(img + NPL * G::APL + i * G::BPL + bbase[tn] + bstep(s));
+    };
+    auto chunk = [&](const unsigned char* cur, unsigned char* nxt, const Src& refill) {
+        u32x4 a[2][TMW][NPL], bo[2][2][NPL];
+        frags(IC<0>{}, IC<0>{}, cur, a, bo);
+        static_for<KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s + 1 < KS) frags(IC<(s + 1) & 1>{}, IC<s + 1>{}, cur, a, bo);
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) mfma_x3(a[s & 1][tm], bo[s & 1][tn], acc[tm][tn], acl[tm][tn]);
+            constexpr int lo = s * NST / KS, hi = (s + 1) * NST / KS;
+            static_for<hi - lo>([&](auto ic) {
+                stage_item(IC<lo + decltype(ic)::value>{}, nxt);
+                load_item(IC<lo + decltype(ic)::value>{}, refill);
+            });
+        });
+    };
+    if (c_begin < c_end) {
+        gload(c_begin);
+        static_for<NST>([&](auto ic) { stage_item(ic, lds); });
+        gload(chunk_of(c_begin + 1));
         __syncthreads();
-        if (ch + 1 < c_end) gload(ch + 1);
-#pragma unroll
-        for (int s = 0; s < PIXC / 16; ++s) {
-            u32x4 a[NPL], bo[2][NPL];
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + i * G::APL + abase + s * 32);
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int i = 0; i < NPL; ++i)
-                    bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * G::BPL + bbase[tn] + bstep(s));
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) mfma_x3(a, bo[tn], acc[tn], acl[tn]);
+        for (int ch = c_begin; ch < c_end; ch += 2) {
+            chunk(lds, lds + G::LDS_BYTES, src_of(chunk_of(ch + 2)));
+            __syncthreads();
+            if (ch + 1 < c_end) {
+                chunk(lds + G::LDS_BYTES, lds, src_of(chunk_of(ch + 3)));
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
 
     const float unscale = F16 ? pow2f(ea) * pow2f(eb) : 1.f;
-    float* out = slab + (int64_t)blockIdx.y * Cs * Cl * 16;
+    float* out = slab + (int64_t)ky * Cs * Cl * 16;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cs = cs0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int cl = cl0 + wn * 4 + tn * 2 + (j >> 4);
-            out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = combine(acc[tn][r], acl[tn][r]) * unscale;
-        }
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int cl = cl0 + wn * 4 + tn * 2 + (j >> 4);
+                out[((int64_t)cs * Cl + cl) * 16 + (j & 15)] = combine(acc[tm][tn][r], acl[tm][tn][r]) * unscale;
+            }
 }
 
 __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ out, int nslab, int64_t len,
@@ -892,13 +969,24 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, float* __restric
     *reinterpret_cast<f32x4*>(out + i4 * 4) = s;
 }
 
-int g_wg_target = 512;   // tuning override: "wg_target"
+int g_wg_target = 0;     // tuning override "wg_target": blocks aimed at (0 = by size)
+int g_wg_bm = 0;         // tuning override "wg_bm": rows of S per block, 64 or 128 (0 = by size)
+
+int wgrad_bm(int hs, int N, int Cs, int Cl) {
+    if (!F16) return 64;        // three planes of a 128-row tile do not fit the LDS twice
+    if (g_wg_bm) return (g_wg_bm == 128 && Cs % 128 == 0) ? 128 : 64;
+    // hs = 4: the two LDS images of a 64-row tile leave room for one block per CU only; a 128-row block does twice the
+    // work with the same L staging (measured 83 against 101 us at N = 256; at N = 64 the 64-row tile's larger grid wins)
+    return (hs == 4 && N >= 128 && Cs % 128 == 0) ? 128 : 64;
+}
 
 template <int HS>
 int wgrad_x3_splits(int N, int Cs, int Cl) {
-    const int tiles = (Cs / 64) * (Cl / 8);
+    const int tiles = (Cs / wgrad_bm(HS, N, Cs, Cl)) * (Cl / 8);
     const int chunks = PixTile<HS, 64>::ntiles(N);
-    int want = (g_wg_target + tiles - 1) / tiles;        // blocks aimed at (512: 2 per CU)
+    // blocks aimed at: as many as are resident at once -- two per CU, one where the two LDS images take over half a CU's LDS
+    const int target = g_wg_target ? g_wg_target : ((HS == 4 || HS == 32) ? 256 : 512);
+    int want = (target + tiles - 1) / tiles;
     if (want > chunks) want = chunks;
     if (want < 1) want = 1;
     const int cpb = (chunks + want - 1) / want;
@@ -909,12 +997,19 @@ template <int HS>
 int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t ws_floats, int N, int Cs, int Cl,
                  int n_keep, int n_swap, int accumulate, hipStream_t st, Bound bs, Bound bl) {
     if (Cs % 64 || Cl % 8) return PGAN_EINVAL;
+    // the kernels address one sample's rows with 32-bit byte offsets (at hs = 4: the whole of L)
+    if ((int64_t)Cs * HS * HS * 64 >= (1ll << 31) || (int64_t)(HS == 4 ? N : 1) * Cl * HS * HS * 16 >= (1ll << 31)) return PGAN_EINVAL;
     const int chunks = PixTile<HS, 64>::ntiles(N);
     const int ns = wgrad_x3_splits<HS>(N, Cs, Cl);
     const int cpb = (chunks + ns - 1) / ns;
     const int64_t len = (int64_t)Cs * Cl * 16;
     if (ns * len > ws_floats) return PGAN_EINVAL;
-    conv_wgrad_x3_kernel<HS><<<dim3((Cs / 64) * (Cl / 8), ns), 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb, bs, bl);
+    if constexpr (F16) if (wgrad_bm(HS, N, Cs, Cl) == 128) {
+        conv_wgrad_x3_kernel<HS, 128><<<(Cs / 128) * (Cl / 8) * ns, 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb, bs, bl);
+        slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len, accumulate);
+        return pgan_launch_status();
+    }
+    conv_wgrad_x3_kernel<HS, 64><<<(Cs / 64) * (Cl / 8) * ns, 256, 0, st>>>(YA, X, ws, N, Cs, Cl, n_keep, n_swap, cpb, bs, bl);
     slab_sum_kernel<<<(int)((len / 4 + 255) / 256), 256, 0, st>>>(ws, dW, ns, len, accumulate);
     return pgan_launch_status();
 }
@@ -1010,7 +1105,8 @@ int FN_SET_OPTION(const char* name, int value) {
     if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_order") && value >= 0 && value <= 2) { g_up_order = value; return PGAN_OK; }
     if (eq(name, "down_order") && value >= 0 && value <= 2) { g_dn_order = value; return PGAN_OK; }
-    if (eq(name, "wg_target") && (value == 0 || (value >= 64 && value <= 4096))) { g_wg_target = value ? value : 512; return PGAN_OK; }
+    if (eq(name, "wg_bm") && (value == 0 || value == 64 || value == 128)) { g_wg_bm = value; return PGAN_OK; }
+    if (eq(name, "wg_target") && (value == 0 || (value >= 64 && value <= 4096))) { g_wg_target = value; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Recompile only the split-operand convolution source (both splits, in parallel) and relink the library.
+set -e
+cd "$(dirname "$0")/../pg-alignments-gan_amd/csrc"
+F="--offload-arch=gfx950 -O3 -std=c++20 -fPIC"
+/opt/rocm/bin/hipcc $F -c conv_x3.hip -o conv_x3.o &
+/opt/rocm/bin/hipcc $F -DPGAN_SPLIT_F16 -c conv_x3.hip -o conv_h2.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpgan_hip.so conv_mfma.o conv_x3.o loader.o norm.o sampling.o small.o tower1d.o conv_h2.o
