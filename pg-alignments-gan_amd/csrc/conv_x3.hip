@@ -687,10 +687,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
     // Blocks that work on the same pixels (one K range, all the output tiles) read the same S rows and L patches: an
-    // XCD gets a contiguous run of the (K range, tile) list, K range slowest, so those re-reads stay in its L2.
-    const int nct = Cl / CLB, ntile = (Cs / BM) * nct;
+    // XCD gets a contiguous run of the (K range, cl tile, cs tile) list, K range slowest, so those re-reads stay in its
+    // L2.  Where one K range's tiles span several runs, each run takes all the cs tiles of some cl tiles: it re-reads
+    // S, which is half the size of L.
+    const int nmt = Cs / BM, ntile = nmt * (Cl / CLB);
     const int b = xcd_remap(blockIdx.x, gridDim.x), ky = b / ntile, tile = b % ntile;
-    const int cs0 = (tile / nct) * BM, cl0 = (tile % nct) * CLB;
+    const int cs0 = (tile % nmt) * BM, cl0 = (tile / nmt) * CLB;
     const int total_chunks = T::ntiles(N);
     const int c_begin = ky * chunks_per_block;
     const int c_end = min(total_chunks, c_begin + chunks_per_block);
