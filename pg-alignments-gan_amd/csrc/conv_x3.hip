@@ -273,7 +273,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     constexpr int CHW = SEG * PR * RSW;                           // dwords per channel per plane
     constexpr int BPL = CLC * CHW;
     constexpr int BUF = NPL * BPL;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    // Waves as WR row groups x WC pixel groups.  A weight fragment goes from L2 into the registers of every wave that uses it,
+    // and that path (64 B/clk per CU) is what the kernel saturates first: with 128 rows every wave takes its own 32
+    // rows over all the block's pixels, so no fragment is loaded twice.
+    constexpr int WR = (BM >= 128) ? 4 : 2, WC = 4 / WR;
+    constexpr int TM = BM / (32 * WR), TN = BN / (32 * WC);
     constexpr int PE = SEG * PR * PCW, NQ = (PE + 255) / 256;
     constexpr int S = CLC * TM * TN;            // micro steps (six MFMAs each) per chunk
     constexpr int NST = CLC * NQ;               // staging items per thread per chunk
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     const int grp = (KG > 1) ? (int)(threadIdx.x >> 8) : 0;
     uint32_t* const lds = lds_all + grp * 2 * BUF;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
+    const int wm = wave / WC, wn = wave % WC, j = lane & 31, h = lane >> 5;
     const int nmt = Cs / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
     // Each XCD gets a contiguous run of b.  cs_major: a run is one row tile (its weight planes stay in that XCD's L2)
@@ -340,10 +344,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     uint32_t abase[TM];
     int bbase[TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) abase[tm] = (uint32_t)((cs0 + wm * (BM / 2) + tm * 32 + j) * 16 + 8 * h);
+    for (int tm = 0; tm < TM; ++tm) abase[tm] = (uint32_t)((cs0 + wm * (BM / WR) + tm * 32 + j) * 16 + 8 * h);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int pt = wn * (BN / WC) + tn * 32 + j;
         const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
         bbase[tn] = (seg * (PR / 2) + ohl + h) * (2 * RSW) + 2 * ow;
     }
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int pt = wn * (BN / 2) + tn * 32 + j;
+        const int pt = wn * (BN / WC) + tn * 32 + j;
         const int seg = pt / (R * WS), rem = pt % (R * WS), ohl = rem / WS, ow = rem % WS;
         const int n = n0 + seg;
         if (n >= N) continue;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int cs = cs0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int cs = cs0 + wm * (BM / WR) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float* dst = Y + (((int64_t)n * Cs + cs) * HS + oh0 + ohl) * WS + ow;
                 float v = combine(acc[tm][tn][r], acl[tm][tn][r]);
                 if constexpr (KG > 1) v += reinterpret_cast<const float*>(lds_all)[((tm * TN + tn) * 16 + r) * 256 + tid];
@@ -1045,6 +1049,7 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
         const int b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
         int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
         if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
+        else if (Cs % 128 == 0 && b4 >= 512 && Cl <= 64) { v = 2; k = 1; }       // short K: one 128x64 block per CU (18.5 against 21.2 us)
         else if (Cs % 128 == 0 && b4 >= 512 && Cl >= 256) { v = 2; k = 2; }      // long K: 128x64 tiles, K over two blocks
         else if (Cs % 128 == 0 && b4 >= 256 && b4 < 512 && Cl >= 128) { v = 2; k = 4; }   // ... over two blocks x two wave groups
         while (k > 1 && Cl % (8 * k)) k >>= 1;
