@@ -13,12 +13,12 @@ Metric: train alignments/sec = critic_iter * global_batch * steps / wall time.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (implicit-GEMM convolutions; all three
-kinds run on the bf16 matrix pipe as six exact partial products per fp32 product): `achieved` counts the MFMA flops
-the family executes on its pipe (six times the algorithmic fp32 flops) against that pipe's dense peak;
-`algorithmic_tflops` is the fp32-equivalent rate.  After the timed region one iteration's launches are noted and
-every launch shape is timed with HIP events on the launch stream around back-to-back launches (eager per-launch
-events would time host launch gaps, and launches inside a replayed graph cannot carry events).  `hbm_kernels` does
-the same for the bandwidth-bound kernels (norms, single-channel convolutions, Adam) against their algorithmic bytes.
+kinds run on the 16-bit matrix pipe: by default as three exact fp16 partial products per fp32 product, with
+PGAN_CONV_PRECISION=x3 as six bf16 ones): `achieved` counts the MFMA flops the family executes on its pipe against
+that pipe's dense peak; `algorithmic_tflops` is the fp32-equivalent rate.  After the timed region one iteration's
+launches are noted and every launch shape is timed with HIP events on the launch stream around back-to-back launches
+replayed from a hipGraph (eager per-launch events would time host launch gaps).  `hbm_kernels` does the same for the
+bandwidth-bound kernels (norms, single-channel convolutions, Adam) against their algorithmic bytes.
 `cpu_baseline` times the CPU oracle (stock PyTorch restatement of the reference step, with the reference's wasted
 backward passes included) on this box's host cores over a bounded sample.
 """
@@ -150,22 +150,45 @@ class RecordingOps:
         return wrapped
 
     def time_shapes(self, reps=20):
-        """Average duration of every recorded launch shape: HIP events on the launch stream around
-        `reps` back-to-back launches (the queue stays full, so host launch latency is not timed)."""
+        """Average duration of every recorded launch shape: HIP events on the launch stream around `reps` back-to-back
+        launches replayed from a hipGraph (no host work between the launches: the shortest kernels here take 3 us, a
+        launch through Python 5-10); shapes whose launches cannot be captured are timed with the queue fed from Python."""
+        from pgan_hip import StepGraph
         out = {}
+        cap = torch.cuda.Stream()
+        if hasattr(self._ops, "reserve_stream"):
+            self._ops.reserve_stream(cap.cuda_stream)
         for key, rec in self.calls.items():
             a, k = rec["args"]
             fn = getattr(self._ops, key[0])
-            for _ in range(3):
-                fn(*a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(reps):
-                fn(*a, **k)
-            e.record()
-            e.synchronize()
+            with torch.cuda.stream(cap):
+                for _ in range(3):
+                    fn(*a, **k)
+                cap.synchronize()
+                graph = StepGraph()
+                self._ops.capturing = True
+                try:
+                    with graph:
+                        for _ in range(reps):
+                            fn(*a, **k)
+                except Exception:
+                    graph = None
+                finally:
+                    self._ops.capturing = False
+                if graph is not None:
+                    graph.launch()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                if graph is not None:
+                    graph.launch()
+                else:
+                    for _ in range(reps):
+                        fn(*a, **k)
+                e.record()
+                e.synchronize()
             ms = s.elapsed_time(e) / reps
-            out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=rec["flops"], bytes=rec["bytes"])
+            out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=rec["flops"], bytes=rec["bytes"],
+                            timed="graph" if graph is not None else "queue")
         return out
 
 
@@ -443,7 +466,7 @@ def main():
             label = cname(k) if single else f"{k[0]}{list(k[1:])}"
             gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             hbm[label] = dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2), algorithmic_MB=round(v["bytes"] / 1e6, 3),
-                              GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4))
+                              GBps=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4), timed=v["timed"])
         roofline = None
         if dom:
             f = fam[dom]
@@ -452,7 +475,7 @@ def main():
             peak = PEAK_FP32_MFMA_TFLOPS if pipe[dom] == "fp32" else PEAK_BF16_MFMA_TFLOPS
             ach = alg * mult
             per_shape = {cname(k): dict(calls=v["calls"], avg_us=round(v["ms"] * 1e3, 2),
-                                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2))
+                                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), timed=v["timed"])
                          for k, v in sorted(conv.items())}
             # HBM traffic of the family's largest launch shape from the committed PMC passes (bytes per launch):
             # rocprofv3 --pmc runs of tools/onekernel.py, separate passes for FETCH_SIZE and WRITE_SIZE; the file names
@@ -484,8 +507,8 @@ def main():
                             algorithmic_ceiling_tflops=round(SUSTAINED_RANDOM_TFLOPS[pipe[dom]] / mult, 1),
                             avg_launch_us=round(f["total_ms"] * 1e3 / f["calls"], 2), launches=f["calls"],
                             flops_per_launch_avg=f["flops"] / f["calls"],
-                            measured=f"HIP events on the launch stream around {args.profile_iters} back-to-back launches "
-                                     f"of every launch shape of one iteration, after the timed region; per-launch "
+                            measured=f"HIP events on the launch stream around {args.profile_iters} back-to-back launches (replayed "
+                                     f"from a hipGraph) of every launch shape of one iteration, after the timed region; per-launch "
                                      f"average weighted by the shape's launches per iteration", families={k: dict(
                                          share_ms_per_iter=round(v["total_ms"], 3), pipe=pipe[k],
                                          algorithmic_tflops=round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2))
