@@ -889,13 +889,16 @@ __global__ __launch_bounds__(1024) void conv_up_c1_kernel(const float* __restric
     }
 }
 
-// WGRAD, Cl = 1: block = (sample, group of 16 cs); wave = 4 cs; lanes sweep the sample's pixels.
-// Writes per-sample partials part[n][cs*16 + tap]; a row reduction finishes the sum.
+// WGRAD, Cl = 1: block = (sample, group of 16 cs); wave = 4 cs.  A lane takes four consecutive pixels of a row per step
+// (one 16-byte load per channel, the next step's loads in flight during the products) and reads the 4 x 10 input values
+// they touch from the staged sample as 8-byte LDS reads.  Writes per-sample partials part[n][cs*16 + tap]; a row
+// reduction finishes the sum.
 template <int HS>
-__global__ __launch_bounds__(256) void conv_wgrad_c1_kernel(const float* __restrict__ YA, const float* __restrict__ X,
+__global__ __launch_bounds__(256, HS == 32 ? 4 : 2) void conv_wgrad_c1_kernel(const float* __restrict__ YA, const float* __restrict__ X,
                                                             float* __restrict__ part, int N, int Cs, int n_keep, int n_swap) {
-    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, PC = WL + 2, PCP = PC | 1;
-    __shared__ float xs[(HL + 2) * PCP];
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, PC = WL + 2, PCP = WL + 4;     // even row stride: 8-byte aligned pairs
+    constexpr int GPR = WS / 4, STEPS = HS * WS / 256;                              // pixel groups per row; steps per wave
+    __shared__ __attribute__((aligned(16))) float xs[(HL + 2) * PCP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngrp = Cs / 16;
     const int n = blockIdx.x / ngrp, cs0 = (blockIdx.x % ngrp) * 16 + wave * 4;
@@ -905,26 +908,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_c1_kernel(const float* __restr
         const int pr = e / PC, pc = e % PC, ih = pr - 1, iw = pc - 1;
         xs[pr * PCP + pc] = (ih >= 0 && ih < HL && iw >= 0 && iw < WL) ? xn[ih * WL + iw] : 0.f;
     }
-    __syncthreads();
     float acc[4][16];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[c][t] = 0.f;
-    const float* ya = YA + ((int64_t)n * Cs + cs0) * HS * WS;
-    for (int p = lane; p < HS * WS; p += 64) {
-        const int oh = p / WS, ow = p % WS;
-        float x[16];
+    const float* ya = YA + ((int64_t)n * Cs + cs0) * HS * WS + 4 * lane;
+    f32x4 y[4], yn[4];
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh)
+    for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const f32x4*>(ya + c * HS * WS);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < STEPS; ++st) {
+        if (st + 1 < STEPS)
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) x[kh * 4 + kw] = xs[(2 * oh + kh) * PCP + 2 * ow + kw];
+            for (int c = 0; c < 4; ++c) yn[c] = *reinterpret_cast<const f32x4*>(ya + c * HS * WS + (st + 1) * 256);
+        const int g = st * 64 + lane, oh = g / GPR, ow0 = (g % GPR) * 4;
+        const float* xr = xs + (2 * oh) * PCP + 2 * ow0;          // input row 2 oh - 1, column 2 ow0 - 1
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float y = ya[c * HS * WS + p];
+        for (int kh = 0; kh < 4; ++kh) {
+            float xv[10];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[c][t] = fmaf(y, x[t], acc[c][t]);
+            for (int i = 0; i < 5; ++i) {
+                const float2 v = *reinterpret_cast<const float2*>(xr + kh * PCP + 2 * i);
+                xv[2 * i] = v.x;
+                xv[2 * i + 1] = v.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) acc[c][kh * 4 + kw] = fmaf(y[c][px], xv[2 * px + kw], acc[c][kh * 4 + kw]);
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = yn[c];
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
