@@ -219,14 +219,14 @@ class FusedTrainer:
         b = self.early_buckets.get(name)
         if b is not None:
             store, lo, hi = b
-            if self._drain:
+            side = getattr(self.eng.side, "stream", None)      # None on the host (CPU op backend)
+            if self._drain or side is None:
                 work = self._sum_over_ranks(store.gflat[lo:hi])
             else:
                 # A blocking collective is enqueued on the caller's current stream; a non-blocking one goes through the
                 # process group's own stream, whose hand-over costs ~30 us of idle queue per call.  The 1-D towers'
                 # stream is idle by now and is joined at the end of the pass, so the bucket is reduced there, beside
                 # the rest of the backward pass.
-                side = self.eng.side.stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     work = self._sum_over_ranks(store.gflat[lo:hi])
