@@ -134,18 +134,21 @@ int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, fl
                        int HW, hipStream_t st);
 int pgan_gn_fwd_static_max_samples(void);
 /* first-order backward (autograd through GroupNorm/LeakyReLU): d = dL/da from u = dL/dh;
- * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta. */
-int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
-                float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, void* ws, long long ws_bytes,
-                int N, int C, int HW, float* amax, hipStream_t st);
+ * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta.
+ * The LeakyReLU mask m (this op, pgan_gn_jvp, pgan_gn_bwd2): with beta == NULL it is read from h, the forward output;
+ * with beta given it is recomputed from a as the forward pass computed it (sign of gamma*xhat + beta) and h is not read
+ * (it may be NULL) -- one tensor fewer to stream in kernels that are bound by the bytes they move. */
+int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
+                float* d, float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, void* ws,
+                long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* tangent (JVP) of the same block: hd from the tangent t of a; stats_t = (mean t, mean xhat*t). */
-int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
+int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
+                float* hd, float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* second-order backward: the piece of autograd's double backward (create_graph=True at
  * src/layers.py:51-53,66-74) that belongs to this block.  hbar may be NULL (= 0). */
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
-                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
+                 const float* stats_b, const float* stats_t, const float* gamma, const float* beta, float* p, float* pg,
+                 float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.1), src/layers.py:93-110,119-135.  a, h: [B][C][HW],
  * HW % 4 == 0; stats: [2][C] = batch mean, rstd; running stats updated in place (unbiased variance). */

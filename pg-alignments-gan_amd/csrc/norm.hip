@@ -132,11 +132,21 @@ __global__ __launch_bounds__(ST) void gn_fwd_apply(const float* __restrict__ a, 
     }
 }
 
+// The backward kernels need the LeakyReLU mask m of the forward output.  MA = false: taken from h.  MA = true: from the
+// sign of gamma xh + beta, the forward pass's own expression on the same a, mean and rstd -- h is then not read at all
+// (these kernels are bound by the bytes they stream: one tensor of three to five fewer per pass).
+template <bool MA>
+__device__ __forceinline__ float mask_of(float hv, float g, float xh, float b) {
+    return MA ? lrelu_mask(g * xh + b) : lrelu_mask(hv);
+}
+
 // first-order backward: d = J (gamma m u); per-sample stats (mean w, mean w xh); per-sample
 // per-channel partial sums of the gamma / beta gradients.
+template <bool MA>
 __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, const float* __restrict__ h,
                                                   const float* __restrict__ a, const float* __restrict__ stats,
-                                                  const float* __restrict__ gamma, float* __restrict__ pg,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ pg,
                                                   float* __restrict__ pb, double* __restrict__ ws, int M, int HW, int C,
                                                   int pld) {
     __shared__ double sh[2 * ST / 64];
@@ -152,12 +162,14 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
     float sw = 0.f, swx = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const int cl = (i * 4) / HW;
-        const float g = gamma[sl.c0 + cl];
-        const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
+        const float g = gamma[sl.c0 + cl], b = MA ? beta[sl.c0 + cl] : 0.f;
+        const f32x4 uv = u4[i], av = a4[i];
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!MA) hv = h4[i];
         float pe[2] = {0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (av[e] - mu) * r, ee = lrelu_mask(hv[e]) * uv[e], w = g * ee;
+            const float xh = (av[e] - mu) * r, ee = mask_of<MA>(hv[e], g, xh, b) * uv[e], w = g * ee;
             sw += w;
             swx += w * xh;
             pe[0] += ee * xh;
@@ -173,9 +185,11 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
         pb[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cb, c);
     }
 }
+template <bool MA>
 __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, const float* __restrict__ h,
                                                    const float* __restrict__ a, const float* __restrict__ stats,
-                                                   const float* __restrict__ gamma, float* __restrict__ d,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ d,
                                                    float* __restrict__ stats_b, const double* __restrict__ ws, int M,
                                                    int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
@@ -193,12 +207,15 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
-        const float g = gamma[sl.c0 + (i * 4) / HW];
-        const f32x4 uv = u4[i], hv = h4[i], av = a4[i];
+        const int c = sl.c0 + (i * 4) / HW;
+        const float g = gamma[c], b = MA ? beta[c] : 0.f;
+        const f32x4 uv = u4[i], av = a4[i];
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!MA) hv = h4[i];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (av[e] - mu) * r, w = g * lrelu_mask(hv[e]) * uv[e];
+            const float xh = (av[e] - mu) * r, w = g * mask_of<MA>(hv[e], g, xh, b) * uv[e];
             o[e] = r * (w - mw - xh * mwx);
         }
         am = amax4(am, o);
@@ -230,9 +247,11 @@ __global__ __launch_bounds__(ST) void gn_jvp_sums(const float* __restrict__ t, c
     double red[2] = {st, sxt};
     put_partials<2>(red, sh, ws, sl);
 }
+template <bool MA>
 __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, const float* __restrict__ h,
                                                    const float* __restrict__ a, const float* __restrict__ stats,
-                                                   const float* __restrict__ gamma, float* __restrict__ hd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float* __restrict__ hd,
                                                    float* __restrict__ stats_t, const double* __restrict__ ws, int M,
                                                    int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
@@ -250,13 +269,16 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
-        const float g = gamma[sl.c0 + (i * 4) / HW];
-        const f32x4 tv = t4[i], hv = h4[i], av = a4[i];
+        const int c = sl.c0 + (i * 4) / HW;
+        const float g = gamma[c], b = MA ? beta[c] : 0.f;
+        const f32x4 tv = t4[i], av = a4[i];
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!MA) hv = h4[i];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (av[e] - mu) * r;
-            o[e] = lrelu_mask(hv[e]) * g * (r * (tv[e] - tb - xh * c_));
+            o[e] = mask_of<MA>(hv[e], g, xh, b) * g * (r * (tv[e] - tb - xh * c_));
         }
         am = amax4(am, o);
         o4[i] = o;
@@ -271,10 +293,12 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
 //   w = gamma m u, q = gamma m hbar, Q = q - r (c w + mwx t)
 //   p = r [ Q - mean Q - xh (mean(Q xh) + mean(w xd)) ],  xd = r (t - tb - xh c)
 // plus per-channel partials  pg = sum m u xd + m hbar xh,  pb = sum m hbar.   hbar may be null (= 0).
+template <bool MA>
 __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hbar, const float* __restrict__ u,
                                                    const float* __restrict__ t, const float* __restrict__ h,
                                                    const float* __restrict__ a, const float* __restrict__ stats,
                                                    const float* __restrict__ stats_t, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta,
                                                    float* __restrict__ pg, float* __restrict__ pb,
                                                    double* __restrict__ ws, int M, int HW, int C, int pld) {
     __shared__ double sh[3 * ST / 64];
@@ -294,12 +318,14 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
     float sq = 0.f, sqx = 0.f, swt = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
         const int cl = (i * 4) / HW;
-        const float g = gamma[sl.c0 + cl];
-        const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        const float g = gamma[sl.c0 + cl], b = MA ? beta[sl.c0 + cl] : 0.f;
+        const f32x4 uv = u4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        f32x4 hv = zero;
+        if constexpr (!MA) hv = h4[i];
         float pe[2] = {0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (av[e] - mu) * r, m = lrelu_mask(hv[e]);
+            const float xh = (av[e] - mu) * r, m = mask_of<MA>(hv[e], g, xh, b);
             const float q = g * m * bv[e], w = g * m * uv[e];
             const float xd = r * (tv[e] - tb - xh * c_);
             sq += q;
@@ -318,11 +344,13 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
         pb[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cb, c);
     }
 }
+template <bool MA>
 __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hbar, const float* __restrict__ u,
                                                     const float* __restrict__ t, const float* __restrict__ h,
                                                     const float* __restrict__ a, const float* __restrict__ stats,
                                                     const float* __restrict__ stats_b, const float* __restrict__ stats_t,
-                                                    const float* __restrict__ gamma, float* __restrict__ p,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ p,
                                                     const double* __restrict__ ws, int M, int HW, int C, float* __restrict__ amax) {
     const Slice sl(M, C);
     double tot[3];
@@ -344,12 +372,15 @@ __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hb
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     float am = 0.f;
     for (int i = sl.tid; i < sl.q; i += ST) {
-        const float g = gamma[sl.c0 + (i * 4) / HW];
-        const f32x4 uv = u4[i], hv = h4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        const int c = sl.c0 + (i * 4) / HW;
+        const float g = gamma[c], b = MA ? beta[c] : 0.f;
+        const f32x4 uv = u4[i], av = a4[i], tv = t4[i], bv = hb4 ? hb4[i] : zero;
+        f32x4 hv = zero;
+        if constexpr (!MA) hv = h4[i];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (av[e] - mu) * r, m = lrelu_mask(hv[e]);
+            const float xh = (av[e] - mu) * r, m = mask_of<MA>(hv[e], g, xh, b);
             const float q = g * m * bv[e], w = g * m * uv[e];
             const float Q = q - r * (c_ * w + mwx * tv[e]);
             o[e] = r * (Q - mQ - xh * kx);
@@ -666,32 +697,45 @@ int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, fl
 }
 int pgan_gn_fwd_static_max_samples(void) { return GN_STATIC_MAX_N; }
 
-int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, float* d,
-                float* stats_b, float* pg, float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW,
+// beta (here and in pgan_gn_jvp / pgan_gn_bwd2) may be null: the LeakyReLU mask is then read from h.  With beta given it
+// is recomputed from a (h may be null and is not read).
+int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
+                float* d, float* stats_b, float* pg, float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW,
                 float* amax, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C || (!beta && !h)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
-    gn_bwd_sums<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, pg, pb, w, C * HW, HW, C, pld);
-    gn_bwd_apply<<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, d, stats_b, w, C * HW, HW, C, amax);
+    if (beta) {
+        gn_bwd_sums<true><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        gn_bwd_apply<true><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, d, stats_b, w, C * HW, HW, C, amax);
+    } else {
+        gn_bwd_sums<false><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        gn_bwd_apply<false><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, d, stats_b, w, C * HW, HW, C, amax);
+    }
     return pgan_launch_status();
 }
 
-int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, float* hd,
-                float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
+int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
+                float* hd, float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || (!beta && !h)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
     gn_jvp_sums<<<N * SL, ST, 0, st>>>(t, a, stats, w, C * HW, C);
-    gn_jvp_apply<<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, hd, stats_t, w, C * HW, HW, C, amax);
+    if (beta) gn_jvp_apply<true><<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, beta, hd, stats_t, w, C * HW, HW, C, amax);
+    else gn_jvp_apply<false><<<N * SL, ST, 0, st>>>(t, h, a, stats, gamma, beta, hd, stats_t, w, C * HW, HW, C, amax);
     return pgan_launch_status();
 }
 
 int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float* h, const float* a, const float* stats,
-                 const float* stats_b, const float* stats_t, const float* gamma, float* p, float* pg, float* pb, int pld,
-                 void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
-    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C) return PGAN_EINVAL;
+                 const float* stats_b, const float* stats_t, const float* gamma, const float* beta, float* p, float* pg,
+                 float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C || (!beta && !h)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
-    gn_bwd2_sums<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, pg, pb, w, C * HW, HW, C, pld);
-    gn_bwd2_apply<<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, w, C * HW, HW, C, amax);
+    if (beta) {
+        gn_bwd2_sums<true><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        gn_bwd2_apply<true><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, beta, p, w, C * HW, HW, C, amax);
+    } else {
+        gn_bwd2_sums<false><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        gn_bwd2_apply<false><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, beta, p, w, C * HW, HW, C, amax);
+    }
     return pgan_launch_status();
 }
 

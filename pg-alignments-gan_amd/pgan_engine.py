@@ -618,10 +618,10 @@ class Engine:
         o = self.ops
         o.head_seed(self.D.p["out.weight"], self.coef_cur[lo:hi], self.dU[self.nS][lo:hi])
         for k in range(self.nS, 0, -1):
-            gw, _ = self.dgn(k)
+            gw, gb = self.dgn(k)      # beta given: the LeakyReLU mask is recomputed from dA, dH is not read
             o.gn_bwd(self.dU[k][lo:hi], self.dH[k][lo:hi], self.dA[k][lo:hi], self.dStat[k][lo:hi], gw,
                      self.dJ[k][lo:hi], self.dStatB[k][lo:hi], self.dPG[k][lo:hi], self.dPB[k][lo:hi],
-                     amax=self.dJmax[k][lo:hi])
+                     amax=self.dJmax[k][lo:hi], beta=gb)
             if k > 1:
                 o.conv_up(self.dJ[k][lo:hi], self.dconv_w(k), self.dU[k - 1][lo:hi], bound=self.dJmax[k][lo:hi])
             elif g_out is not None:
@@ -754,19 +754,19 @@ class Engine:
         pl, ph = NS - NP, NS
         for k in range(1, nS + 1):
             o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT], bound=self._hmax(k - 1, NS, NT))
-            gw_k, _ = self.dgn(k)
+            gw_k, gb_k = self.dgn(k)
             o.gn_jvp(self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph], self.dStat[k][pl:ph], gw_k,
-                     self.dH[k][NS:NT], self.dStatT[k][NS:NT], amax=self.dHmax[k][NS:NT])
+                     self.dH[k][NS:NT], self.dStatT[k][NS:NT], amax=self.dHmax[k][NS:NT], beta=gb_k)
         # second-order backward of the penalised samples
         hbar = None
         if self.loss == "div":
             o.head_seed(Dp["out.weight"], self.coef_top, self.HB4)
             hbar = self.HB4
         for k in range(nS, 0, -1):
-            gw_k, _ = self.dgn(k)
+            gw_k, gb_k = self.dgn(k)
             o.gn_bwd2(hbar, self.dU[k][pl:ph], self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph],
                       self.dStat[k][pl:ph], self.dStatB[k][pl:ph], self.dStatT[k][NS:NT], gw_k,
-                      self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT], amax=self.dJmax[k][NS:NT])
+                      self.dJ[k][NS:NT], self.dPG[k][NS:NT], self.dPB[k][NS:NT], amax=self.dJmax[k][NS:NT], beta=gb_k)
             # stage k's adjoints are complete over all 4B slots: its weight-gradient pass (one per stage,
             # over all slots) runs on its own stream beside the rest of the chain
             self.wside.fork()

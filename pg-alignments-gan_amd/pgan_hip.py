@@ -48,10 +48,10 @@ _SIGS = {
     "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P, P],
-    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
+    "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
-    "pgan_gn_jvp": [P, P, P, P, P, P, P, P, L, I, I, I, P, P],
-    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
+    "pgan_gn_jvp": [P, P, P, P, P, P, P, P, P, L, I, I, I, P, P],
+    "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
     "pgan_bn_fwd": [P, P, P, P, P, P, P, P, L, I, I, I, F, I, P, P],
     "pgan_bn_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P, P],
     "pgan_bn_fwd_sums": [P, P, I, I, I, I, P, P],
@@ -488,21 +488,22 @@ class HipOps:
         _check(_lib.pgan_gn_fwd_static(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), N, C, _hw(a), _stream()),
                "pgan_gn_fwd_static")
 
-    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None):
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None, beta=None):
+        """beta (gn_bwd, gn_jvp, gn_bwd2): given, the LeakyReLU mask is recomputed from a and h is not read."""
         N, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(d), _ptr(stats_b),
+        _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(d), _ptr(stats_b),
                                 _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd")
 
-    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None):
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
-        _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(hd), _ptr(stats_t),
+        _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(hd), _ptr(stats_t),
                                 *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_jvp")
 
-    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None):
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
-                                 _ptr(stats_t), _ptr(gamma), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
+                                 _ptr(stats_t), _ptr(gamma), _ptr(beta), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
                                  *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd2")
 
     # ---------------- BatchNorm ----------------

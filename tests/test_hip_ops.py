@@ -341,8 +341,10 @@ def test_conv_c1(hip, N, act, Cs, hs):
 GN_SHAPES = [(64, 32), (128, 16), (256, 8), (512, 4), (32, 64)]
 
 
+@pytest.mark.parametrize("mask_from", ["h", "a"])
 @pytest.mark.parametrize("C,hs", GN_SHAPES + [(256, 4)])
-def test_groupnorm_family(hip, C, hs):
+def test_groupnorm_family(hip, C, hs, mask_from):
+    """mask_from = "a": the backward ops get beta and recompute the LeakyReLU mask from a; they are handed no h at all."""
     rng = np.random.default_rng(5)
     N = 3
     sh = (N, C, hs, hs)
@@ -359,13 +361,14 @@ def test_groupnorm_family(hip, C, hs):
     close("gn_fwd.h", h_g, h_w)
     close("gn_fwd.stats", st_g, st_w)
     h32 = h_g.cpu()   # masks come from the GPU's own forward output
+    h_in, mk = (h_g, {}) if mask_from == "h" else (None, dict(beta=beta.to(DEV)))
     # first-order backward
     d_w, sb_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
     pg_w, pb_w = torch.zeros(N, C, dtype=torch.float64), torch.zeros(N, C, dtype=torch.float64)
     REF.gn_bwd(*d64(u, h32, a), st_w, gamma.double(), d_w, sb_w, pg_w, pb_w)
     d_g, sb_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
     pg_g, pb_g = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV)
-    hip.gn_bwd(*gpu(u), h_g, a.to(DEV), st_g, gamma.to(DEV), d_g, sb_g, pg_g, pb_g, amax=am)
+    hip.gn_bwd(*gpu(u), h_in, a.to(DEV), st_g, gamma.to(DEV), d_g, sb_g, pg_g, pb_g, amax=am, **mk)
     assert torch.equal(am, _slice_amax(d_g))
     close("gn_bwd.d", d_g, d_w)
     close("gn_bwd.pg", pg_g, pg_w)
@@ -374,7 +377,7 @@ def test_groupnorm_family(hip, C, hs):
     hd_w, stt_w = torch.zeros(sh, dtype=torch.float64), torch.zeros(N, 2, dtype=torch.float64)
     REF.gn_jvp(*d64(t, h32, a), st_w, gamma.double(), hd_w, stt_w)
     hd_g, stt_g = torch.zeros(sh, device=DEV), torch.zeros(N, 2, device=DEV)
-    hip.gn_jvp(t.to(DEV), h_g, a.to(DEV), st_g, gamma.to(DEV), hd_g, stt_g, amax=am)
+    hip.gn_jvp(t.to(DEV), h_in, a.to(DEV), st_g, gamma.to(DEV), hd_g, stt_g, amax=am, **mk)
     assert torch.equal(am, _slice_amax(hd_g))
     close("gn_jvp.hd", hd_g, hd_w)
     # second-order backward, with and without an incoming primal adjoint
@@ -383,8 +386,8 @@ def test_groupnorm_family(hip, C, hs):
         REF.gn_bwd2(None if hb is None else hb.double(), *d64(u, t, h32, a), st_w, sb_w, stt_w, gamma.double(), p_w,
                     pg_w, pb_w)
         p_g = torch.zeros(sh, device=DEV)
-        hip.gn_bwd2(None if hb is None else hb.to(DEV), u.to(DEV), t.to(DEV), h_g, a.to(DEV), st_g, sb_g, stt_g,
-                    gamma.to(DEV), p_g, pg_g, pb_g, amax=am)
+        hip.gn_bwd2(None if hb is None else hb.to(DEV), u.to(DEV), t.to(DEV), h_in, a.to(DEV), st_g, sb_g, stt_g,
+                    gamma.to(DEV), p_g, pg_g, pb_g, amax=am, **mk)
         assert torch.equal(am, _slice_amax(p_g))
         close("gn_bwd2.p", p_g, p_w, rtol=2e-5)
         close("gn_bwd2.pg", pg_g, pg_w, rtol=2e-5)

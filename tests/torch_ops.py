@@ -83,7 +83,7 @@ class TorchOps:
         sh = (-1,) + (1,) * (a.dim() - 1)
         return (a - stats[:, 0].view(sh)) * stats[:, 1].view(sh), stats[:, 1].view(sh)
 
-    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None):
+    def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None, beta=None):      # beta: the HIP ops' switch to a mask recomputed from a; the mask is the same
         xh, r = self._xhat(a, stats)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
         e = _mask(h) * u
@@ -97,7 +97,7 @@ class TorchOps:
         pg.copy_((e * xh).sum(red))
         pb.copy_(e.sum(red))
 
-    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None):
+    def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None, beta=None):
         xh, r = self._xhat(a, stats)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
         tb, c = _mean(t), _mean(xh * t)
@@ -106,7 +106,7 @@ class TorchOps:
         stats_t[:, 0] = tb.flatten()
         stats_t[:, 1] = c.flatten()
 
-    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None):
+    def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None, beta=None):
         xh, r = self._xhat(a, stats)
         sh = (-1,) + (1,) * (a.dim() - 1)
         g = gamma.view(1, -1, *([1] * (a.dim() - 2)))
