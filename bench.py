@@ -119,8 +119,9 @@ class RecordingOps:
     DESCRIBE = {
         "conv_down": _conv.__func__("conv_down"), "conv_up": _conv.__func__("conv_up"),
         "conv_wgrad": _conv.__func__("conv_wgrad"),
-        "gn_fwd": _stream_op.__func__("gn_fwd", 2), "gn_bwd": _stream_op.__func__("gn_bwd", 4),
-        "gn_jvp": _stream_op.__func__("gn_jvp", 4), "gn_bwd2": _stream_op.__func__("gn_bwd2", 6),
+        # the GroupNorm backward ops recompute the LeakyReLU mask from the pre-norm input: the forward output is not read
+        "gn_fwd": _stream_op.__func__("gn_fwd", 2), "gn_bwd": _stream_op.__func__("gn_bwd", 3),
+        "gn_jvp": _stream_op.__func__("gn_jvp", 3), "gn_bwd2": _stream_op.__func__("gn_bwd2", 5),
         "bn_fwd": _stream_op.__func__("bn_fwd", 2), "bn_bwd": _stream_op.__func__("bn_bwd", 4),
         "adam": lambda a, k: (("adam", _numel(a[0])), 0.0, 28.0 * _numel(a[0])),
     }
