@@ -182,15 +182,19 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
     }
 }
 
-// L0 = 128: the last stage's weights (32 KB) stay in global memory -- with them the kernel's LDS would exceed a CU's.
+// One block per sample, a serial chain of small phases: the kernel is latency-bound and runs beside the 2-D towers'
+// convolutions on another stream, so what it holds of a CU matters more than its own speed.  The last stage's weights
+// (32 KB) stay in global memory (L0 = 128: with them the LDS would exceed a CU's; L0 = 64: with them and the 256 registers
+// the compiler then takes, one block would own a whole CU -- registers and 104 KB of LDS -- and every convolution block
+// would wait for it); at 71 KB and 128 registers it leaves half a CU to the other streams.
 template <int D1_L0>
-__global__ __launch_bounds__(512) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
+__global__ __launch_bounds__(512, 4) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
                                                       const float* __restrict__ a1s, const float* __restrict__ a2s,
                                                       const float* __restrict__ a3s, const float* __restrict__ coef,
                                                       const float* __restrict__ w_tail, float* __restrict__ part,
                                                       int part_ld, D1Offsets off, float* __restrict__ dxp) {
     constexpr int D1_L1 = D1_L0 - 3, D1_L2 = D1_L0 - 6, D1_L3 = D1_L0 - 9;
-    constexpr bool W3_LDS = D1_L0 <= 64;
+    constexpr bool W3_LDS = false;
     __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], h1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], h2[D1_C2 * D1_L2],
         a3[D1_C3 * D1_L3], g3[D1_C3 * D1_L3], g2[D1_C2 * D1_L2], g1[D1_C1 * D1_L1], g0[D1_L0];
