@@ -150,13 +150,14 @@ class RecordingOps:
             return fn(*a, **k)
         return wrapped
 
-    def time_shapes(self, reps=20):
+    def time_shapes(self, reps=20, stream=None):
         """Average duration of every recorded launch shape: HIP events on the launch stream around `reps` back-to-back
         launches replayed from a hipGraph (no host work between the launches: the shortest kernels here take 3 us, a
-        launch through Python 5-10); shapes whose launches cannot be captured are timed with the queue fed from Python."""
+        launch through Python 5-10); shapes whose launches cannot be captured are timed with the queue fed from Python.
+        stream: an existing (idle) stream to capture on -- a new one would shift which hardware queue later streams get."""
         from pgan_hip import StepGraph
         out = {}
-        cap = torch.cuda.Stream()
+        cap = stream if stream is not None else torch.cuda.Stream()
         if hasattr(self._ops, "reserve_stream"):
             self._ops.reserve_stream(cap.cuda_stream)
         for key, rec in self.calls.items():
@@ -440,7 +441,7 @@ def main():
     tr.iteration()
     timed.recording = False
     torch.cuda.synchronize()
-    summ = timed.time_shapes(args.profile_iters)
+    summ = timed.time_shapes(args.profile_iters, stream=getattr(tr.eng.side, "stream", None))
 
     if rank == 0:
         conv = {k: v for k, v in summ.items() if k[0].startswith("conv_")}

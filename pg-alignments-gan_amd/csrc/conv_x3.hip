@@ -667,7 +667,9 @@ struct WgGeom {
     static constexpr int CHB = (HS == 4) ? 16 * 32 : 4 * KWB + (HS == 16 ? 16 : (HS == 32 ? 192 : 0));        // bytes per (segment,) channel
     static constexpr int BPL = (HS == 4) ? SEG * CLB * CHB : CLB * CHB;
     static constexpr int LDS_BYTES = NPL * APL + NPL * BPL;
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "LDS of one CU");
+    static constexpr bool PIPE = F16;           // two LDS images and a software-pipelined K loop (two planes only)
+    static constexpr int IMAGES = PIPE ? 2 : 1;
+    static_assert(IMAGES * LDS_BYTES <= 160 * 1024, "LDS of one CU");
     // staging items of the L side
     static constexpr int NIB = (HS == 4) ? SEG * CLB * 4 * 4 : CLB * PRR * (WS / 2);
     static constexpr int NQB = (NIB + 255) / 256;
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
     constexpr int AV = BM * PIXC / 4 / 256;          // f32x4 of the S tile per thread
     constexpr int TMW = BM / 64;                     // 32-row tiles per wave
     constexpr int NQB = G::NQB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::LDS_BYTES];      // two images of a chunk
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::IMAGES * G::LDS_BYTES];      // image(s) of a chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, j = lane & 31, h = lane >> 5;
@@ -936,18 +938,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
             });
         });
     };
-    if (c_begin < c_end) {
-        gload(c_begin);
-        static_for<NST>([&](auto ic) { stage_item(ic, lds); });
-        gload(chunk_of(c_begin + 1));
-        __syncthreads();
-        for (int ch = c_begin; ch < c_end; ch += 2) {
-            chunk(lds, lds + G::LDS_BYTES, src_of(chunk_of(ch + 2)));
+    if constexpr (G::PIPE) {
+        if (c_begin < c_end) {
+            gload(c_begin);
+            static_for<NST>([&](auto ic) { stage_item(ic, lds); });
+            gload(chunk_of(c_begin + 1));
             __syncthreads();
-            if (ch + 1 < c_end) {
-                chunk(lds + G::LDS_BYTES, lds, src_of(chunk_of(ch + 3)));
+            for (int ch = c_begin; ch < c_end; ch += 2) {
+                chunk(lds, lds + G::LDS_BYTES, src_of(chunk_of(ch + 2)));
                 __syncthreads();
+                if (ch + 1 < c_end) {
+                    chunk(lds + G::LDS_BYTES, lds, src_of(chunk_of(ch + 3)));
+                    __syncthreads();
+                }
             }
+        }
+    } else {
+        // three planes: two images would leave one block per CU; one image, staged and consumed in turn, and the two or three
+        // co-resident blocks overlap each other's phases instead
+        if (c_begin < c_end) gload(c_begin);
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            static_for<NST>([&](auto ic) { stage_item(ic, lds); });
+            __syncthreads();
+            if (ch + 1 < c_end) gload(ch + 1);
+            u32x4 a[2][TMW][NPL], bo[2][2][NPL];
+            static_for<KS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                frags(IC<0>{}, sc, lds, a, bo);
+#pragma unroll
+                for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) mfma_x3(a[0][tm], bo[0][tn], acc[tm][tn], acl[tm][tn]);
+            });
+            __syncthreads();
         }
     }
 
@@ -991,7 +1014,7 @@ int wgrad_x3_splits(int N, int Cs, int Cl) {
     const int tiles = (Cs / wgrad_bm(HS, N, Cs, Cl)) * (Cl / 8);
     const int chunks = PixTile<HS, 64>::ntiles(N);
     // blocks aimed at: as many as are resident at once -- two per CU, one where the two LDS images take over half a CU's LDS
-    const int target = g_wg_target ? g_wg_target : ((HS == 4 || HS == 32) ? 256 : 512);
+    const int target = g_wg_target ? g_wg_target : ((F16 && (HS == 4 || HS == 32)) ? 256 : 512);
     int want = (target + tiles - 1) / tiles;
     if (want > chunks) want = chunks;
     if (want < 1) want = 1;
