@@ -154,7 +154,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
     const Slice sl(M, C);
     const int GL = min(64, HW / 4), cps = C / SL;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     for (int c = sl.tid; c < CW * 64; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
         stats_b[2 * sl.n + 1] = mwx;
     }
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* d4 = reinterpret_cast<f32x4*>(d + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
         stats_t[2 * sl.n + 1] = c_;
     }
     const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* o4 = reinterpret_cast<f32x4*>(hd + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
     const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
     const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
     const float tb = stats_t[2 * sl.n], c_ = stats_t[2 * sl.n + 1];
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_apply(const float* __restrict__ hb
     const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
     const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
-    const f32x4* h4 = reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
     f32x4* p4 = reinterpret_cast<f32x4*>(p + sl.base);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
