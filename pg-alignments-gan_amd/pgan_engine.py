@@ -262,8 +262,9 @@ class Engine:
         self.bn_world = 1
         self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
         # weight gradients of the Wasserstein samples right after their backward, the penalised samples' share added
-        # later (two half-size passes per stage instead of one): measured slightly slower, kept as an option
-        self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "0") == "1"
+        # later (two half-size passes per stage instead of one): the first half leaves the weight-gradient stream early,
+        # beside the penalty chain (7.26 -> 7.10 ms per iteration; PGAN_SPLIT_WGRAD=0: one pass over all slots)
+        self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "1") != "0"
         self._bn_parts = {}
         # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
         # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
