@@ -1005,8 +1005,8 @@ int wgrad_bm(int hs, int N, int Cs, int Cl) {
     if (!F16) return 64;        // three planes of a 128-row tile do not fit the LDS twice
     if (g_wg_bm) return (g_wg_bm == 128 && Cs % 128 == 0) ? 128 : 64;
     // hs = 4: the two LDS images of a 64-row tile leave room for one block per CU only; a 128-row block does twice the
-    // work with the same L staging (measured 83 against 101 us at N = 256; at N = 64 the 64-row tile's larger grid wins)
-    return (hs == 4 && N >= 128 && Cs % 128 == 0) ? 128 : 64;
+    // work with the same L staging (measured 75 against 101 us at N = 256, 31.8 against 34.9 at N = 64)
+    return (hs == 4 && Cs % 128 == 0) ? 128 : 64;
 }
 
 template <int HS>
