@@ -5,6 +5,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 
 LAYER = {16: (128, 64), 8: (256, 128), 4: (512, 256)}
@@ -20,7 +21,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_*_f")):
         fs = glob.glob(d[:-1] + part + "/*/*counter_collection.csv")
         if not fs:
             continue
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):      # the latest pass of that shape
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
