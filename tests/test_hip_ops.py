@@ -311,6 +311,32 @@ def test_conv_wgrad(hip, Cs, Cl, hs, N, keep, swap, pipe):
     close("conv_wgrad.accumulate", acc, want + base.double())
 
 
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
+@pytest.mark.parametrize("bm,target", [(64, 64), (64, 1024), (128, 64), (128, 256), (128, 1024)])
+def test_conv_wgrad_tiles(hip, Cs, Cl, hs, bm, target):
+    """Every tile height of the fp16-split WGRAD kernel at every stage size, from one block per output tile (all chunks
+    in one K range: the pipelined loop's long even / odd runs) to one chunk per block."""
+    from pgan_hip import set_x3_option
+    if bm == 128 and Cs % 128:
+        pytest.skip("128-row tiles need Cs % 128 == 0")
+    rng = np.random.default_rng(11)
+    N, keep, swap = 21, 7, 7
+    ya, x = rnd(rng, N, Cs, hs, hs), rnd(rng, N, Cl, 2 * hs, 2 * hs)
+    want = torch.zeros(Cs, Cl, 4, 4, dtype=torch.float64)
+    REF.conv_wgrad(*d64(ya, x), want, keep, swap)
+    got = torch.full((Cs, Cl, 4, 4), float("nan"), device=DEV)
+    hip.precision = "h2"
+    try:
+        set_x3_option("wg_bm", bm)
+        set_x3_option("wg_target", target)
+        hip.conv_wgrad(*gpu(ya, x), got, keep, swap)
+    finally:
+        set_x3_option("wg_bm", 0)
+        set_x3_option("wg_target", 0)
+        hip.precision = "x3"
+    close("conv_wgrad", got, want)
+
+
 @pytest.mark.parametrize("Cs,hs", [(64, 32), (32, 64)])
 @pytest.mark.parametrize("N", [1, 3])
 @pytest.mark.parametrize("act", [0, 1, 2])
