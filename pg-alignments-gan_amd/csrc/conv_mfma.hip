@@ -956,24 +956,39 @@ __global__ __launch_bounds__(256, HS == 32 ? 4 : 2) void conv_wgrad_c1_kernel(co
 }
 
 // out[c] (+)= sum_r coef[r] * part[r * ld + c] over rows [r0, r1) and [r2, r3) (coef == nullptr: 1).
-// Block = 32 columns x 8 row lanes; rows are strided over the lanes and combined through LDS.
-__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int ld,
-                                                       const float* __restrict__ coef, float* __restrict__ out, int C,
-                                                       int r0, int r1, int r2, int r3, int accumulate) {
-    __shared__ float sh[8][33];
+// Block = 32 columns x RL row lanes (1024 threads): the rows are strided over the lanes, four loads in flight per lane,
+// and combined through LDS in a fixed order.  These launches have few columns (a few thousand) and up to a few hundred
+// rows: they are bound by how many loads are in flight, not by bytes.
+constexpr int RL = 32;
+__device__ __forceinline__ float rows_partial(const float* __restrict__ part, int ld, const float* __restrict__ coef, int c,
+                                              int lo, int hi, int ry) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = lo + ry;
+    for (; r + 3 * RL < hi; r += 4 * RL) {
+        const float v0 = part[(int64_t)r * ld + c], v1 = part[(int64_t)(r + RL) * ld + c];
+        const float v2 = part[(int64_t)(r + 2 * RL) * ld + c], v3 = part[(int64_t)(r + 3 * RL) * ld + c];
+        s0 = fmaf(coef ? coef[r] : 1.f, v0, s0);
+        s1 = fmaf(coef ? coef[r + RL] : 1.f, v1, s1);
+        s2 = fmaf(coef ? coef[r + 2 * RL] : 1.f, v2, s2);
+        s3 = fmaf(coef ? coef[r + 3 * RL] : 1.f, v3, s3);
+    }
+    for (; r < hi; r += RL) s0 = fmaf(coef ? coef[r] : 1.f, part[(int64_t)r * ld + c], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(32 * RL) void rows_sum_kernel(const float* __restrict__ part, int ld,
+                                                           const float* __restrict__ coef, float* __restrict__ out, int C,
+                                                           int r0, int r1, int r2, int r3, int accumulate) {
+    __shared__ float sh[RL][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     float s = 0.f;
-    if (c < C) {
-        for (int r = r0 + ry; r < r1; r += 8) s = fmaf(coef ? coef[r] : 1.f, part[(int64_t)r * ld + c], s);
-        for (int r = r2 + ry; r < r3; r += 8) s = fmaf(coef ? coef[r] : 1.f, part[(int64_t)r * ld + c], s);
-    }
+    if (c < C) s = rows_partial(part, ld, coef, c, r0, r1, ry) + rows_partial(part, ld, coef, c, r2, r3, ry);
     sh[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && c < C) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        for (int k = 0; k < RL; ++k) t += sh[k][cx];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -993,8 +1008,8 @@ struct RowSegs {
     int ld[4];
     int C[4];
 };
-__global__ __launch_bounds__(256) void rows_sum_multi_kernel(RowSegs sg, int r0, int r1, int r2, int r3) {
-    __shared__ float sh[8][33];
+__global__ __launch_bounds__(32 * RL) void rows_sum_multi_kernel(RowSegs sg, int r0, int r1, int r2, int r3) {
+    __shared__ float sh[RL][33];
     const int seg = blockIdx.y;
     const int C = sg.C[seg], ld = sg.ld[seg];
     const float* part = sg.part[seg];
@@ -1002,16 +1017,13 @@ __global__ __launch_bounds__(256) void rows_sum_multi_kernel(RowSegs sg, int r0,
     const int c = blockIdx.x * 32 + cx;
     if (blockIdx.x * 32 >= C) return;
     float s = 0.f;
-    if (c < C) {
-        for (int r = r0 + ry; r < r1; r += 8) s += part[(int64_t)r * ld + c];
-        for (int r = r2 + ry; r < r3; r += 8) s += part[(int64_t)r * ld + c];
-    }
+    if (c < C) s = rows_partial(part, ld, nullptr, c, r0, r1, ry) + rows_partial(part, ld, nullptr, c, r2, r3, ry);
     sh[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && c < C) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][cx];
+        for (int k = 0; k < RL; ++k) t += sh[k][cx];
         sg.out[seg][c] = t;
     }
 }
@@ -1178,7 +1190,7 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
         if ((hs != 32 && hs != 64) || Cs % 16 || (long long)N * Cs * 16 > ws_floats) return PGAN_EINVAL;
         if (hs == 32) conv_wgrad_c1_kernel<32><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
         else conv_wgrad_c1_kernel<64><<<N * (Cs / 16), 256, 0, st>>>(S, L, ws, N, Cs, n_keep, n_swap);
-        rows_sum_kernel<<<(Cs * 16 + 31) / 32, 256, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, accumulate);
+        rows_sum_kernel<<<(Cs * 16 + 31) / 32, 32 * RL, 0, st>>>(ws, Cs * 16, nullptr, dW, Cs * 16, 0, N, 0, 0, accumulate);
         return pgan_launch_status();
     }
     switch (hs) {
@@ -1193,7 +1205,7 @@ int pgan_conv_wgrad(const float* S, const float* L, float* dW, float* ws, long l
 int pgan_rows_reduce(const float* part, int ld, float* out, int C, int r0, int r1, int r2, int r3, int accumulate,
                      hipStream_t st) {
     if (C <= 0 || ld < C) return PGAN_EINVAL;
-    rows_sum_kernel<<<(C + 31) / 32, 256, 0, st>>>(part, ld, nullptr, out, C, r0, r1, r2, r3, accumulate);
+    rows_sum_kernel<<<(C + 31) / 32, 32 * RL, 0, st>>>(part, ld, nullptr, out, C, r0, r1, r2, r3, accumulate);
     return pgan_launch_status();
 }
 
@@ -1209,14 +1221,14 @@ int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const
         sg.part[i] = part[k]; sg.out[i] = out[k]; sg.ld[i] = ld[k]; sg.C[i] = C[k];
         if (C[k] > cmax) cmax = C[k];
     }
-    rows_sum_multi_kernel<<<dim3((cmax + 31) / 32, nseg), 256, 0, st>>>(sg, r0, r1, r2, r3);
+    rows_sum_multi_kernel<<<dim3((cmax + 31) / 32, nseg), 32 * RL, 0, st>>>(sg, r0, r1, r2, r3);
     return pgan_launch_status();
 }
 
 // dw[j] = sum_n coef[n] * x[n * J + j]: weight gradient of the linear head and its bias.
 int pgan_head_wgrad(const float* x, const float* coef, float* dw, int N, int J, hipStream_t st) {
     if (N <= 0 || J <= 0) return PGAN_EINVAL;
-    rows_sum_kernel<<<(J + 31) / 32, 256, 0, st>>>(x, J, coef, dw, J, 0, N, 0, 0, 0);
+    rows_sum_kernel<<<(J + 31) / 32, 32 * RL, 0, st>>>(x, J, coef, dw, J, 0, N, 0, 0, 0);
     return pgan_launch_status();
 }
 
