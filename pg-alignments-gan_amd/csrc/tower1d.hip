@@ -149,6 +149,7 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
             const float* ip = in + ci * LI;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             float x0 = ip[0], x1 = ip[1], x2 = ip[2];
+#pragma unroll 5
             for (int l = 0; l < LO; ++l) {
                 const float x3 = ip[l + 3], dv = dp[l];
                 s0 = fmaf(dv, x0, s0);
@@ -169,6 +170,7 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
         for (int idx = threadIdx.x; idx < CI * LI; idx += blockDim.x) {
             const int ci = idx / LI, li = idx % LI;
             float s = 0.f;
+#pragma unroll 4
             for (int co = 0; co < CO; ++co) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (co * CI + ci) * 4);
                 const float* dp = d + co * LO + li;
@@ -183,10 +185,11 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
 }
 
 // One block per sample, a serial chain of small phases: the kernel is latency-bound and runs beside the 2-D towers'
-// convolutions on another stream, so what it holds of a CU matters more than its own speed.  The last stage's weights
-// (32 KB) stay in global memory (L0 = 128: with them the LDS would exceed a CU's; L0 = 64: with them and the 256 registers
-// the compiler then takes, one block would own a whole CU -- registers and 104 KB of LDS -- and every convolution block
-// would wait for it); at 71 KB and 128 registers it leaves half a CU to the other streams.
+// convolutions on another stream, so what it holds of a CU matters more than its own speed.  Fully unrolled, its inner
+// loops took all 256 registers per lane: with its 104 KB of LDS one block then owned a whole CU and every convolution
+// block waited for it.  The loops are unrolled by 4-5 (161 registers, no spills): a third of the register file and
+// 56 KB of LDS stay free for the other streams' blocks.
+// L0 = 128: the last stage's weights (32 KB) stay in global memory -- with them the kernel's LDS would exceed a CU's.
 template <int D1_L0>
 __global__ __launch_bounds__(512, 4) void d1d_bwd_kernel(const float* __restrict__ xp, D1Params P,
                                                       const float* __restrict__ a1s, const float* __restrict__ a2s,
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(512, 4) void d1d_bwd_kernel(const float* __restrict
                                                       const float* __restrict__ w_tail, float* __restrict__ part,
                                                       int part_ld, D1Offsets off, float* __restrict__ dxp) {
     constexpr int D1_L1 = D1_L0 - 3, D1_L2 = D1_L0 - 6, D1_L3 = D1_L0 - 9;
-    constexpr bool W3_LDS = false;
+    constexpr bool W3_LDS = D1_L0 <= 64;
     __shared__ double sh[32];
     __shared__ float x0[D1_L0], a1[D1_C1 * D1_L1], h1[D1_C1 * D1_L1], a2[D1_C2 * D1_L2], h2[D1_C2 * D1_L2],
         a3[D1_C3 * D1_L3], g3[D1_C3 * D1_L3], g2[D1_C2 * D1_L2], g1[D1_C1 * D1_L1], g0[D1_L0];
