@@ -263,6 +263,7 @@ __global__ void ct1d_up_kernel(const float* __restrict__ y, const float* __restr
         const int o2 = i + 1 - k;
         if (o2 < 0 || (o2 & 1) || o2 / 2 >= Ls) continue;
         const int o = o2 / 2;
+#pragma unroll 8
         for (int cs = 0; cs < Cs; ++cs) s = fmaf(y[((int64_t)n * Cs + cs) * Ls + o], w[(cs * Cl + cl) * 4 + k], s);
     }
     if (act == 1) s = 1.f / (1.f + expf(-s));
@@ -277,6 +278,7 @@ __global__ void ct1d_down_kernel(const float* __restrict__ x, const float* __res
     if (idx >= (int64_t)N * Cs * Ls) return;
     const int o = (int)(idx % Ls), cs = (int)((idx / Ls) % Cs), n = (int)(idx / ((int64_t)Ls * Cs));
     float s = 0.f;
+#pragma unroll 4
     for (int cl = 0; cl < Cl; ++cl) {
         const float* xp = x + ((int64_t)n * Cl + cl) * Ll;
         const float* wp = w + (cs * Cl + cl) * 4;
