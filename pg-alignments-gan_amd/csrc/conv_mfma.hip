@@ -849,12 +849,18 @@ __global__ __launch_bounds__(1024) void conv_up_c1_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int n = blockIdx.x / (HS / RT), a0 = (blockIdx.x % (HS / RT)) * RT;
     for (int i = tid; i < Cs * 16; i += 1024) ws[i] = W[i];
-    for (int e = tid; e < Cs * PR * PC; e += 1024) {
-        const int c = e / (PR * PC), rem = e % (PR * PC), pr = rem / PC, pc = rem % PC;
-        const int a = a0 - 1 + pr, b = pc - 1;
-        ys[(c * PR + pr) * PCP + pc] = (a >= 0 && a < HS && b >= 0 && b < WS)
-                                           ? Y[(((int64_t)n * Cs + c) * HS + a) * WS + b] : 0.f;
+    // the patch rows are whole image rows: 16-byte loads (WS / 4 per row, a few per thread, all in flight together);
+    // the two halo columns are always outside the image
+    constexpr int QR = WS / 4;
+    const float* yn = Y + (int64_t)n * Cs * HS * WS;
+    for (int i = tid; i < Cs * PR * QR; i += 1024) {
+        const int c = i / (PR * QR), pr = (i / QR) % PR, q = i % QR, a = a0 - 1 + pr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a >= 0 && a < HS) v = *reinterpret_cast<const f32x4*>(yn + ((int64_t)c * HS + a) * WS + 4 * q);
+        float* dst = ys + (c * PR + pr) * PCP + 1 + 4 * q;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
     }
+    for (int i = tid; i < Cs * PR * 2; i += 1024) ys[(i >> 1) * PCP + (i & 1) * (PC - 1)] = 0.f;
     __syncthreads();
     const int g = tid / PX, p = tid % PX, al = p / WS, bl = p % WS, cpg = Cs / NG;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -906,10 +912,15 @@ __global__ __launch_bounds__(256, HS == 32 ? 4 : 2) void conv_wgrad_c1_kernel(co
     const int n = blockIdx.x / ngrp, cs0 = (blockIdx.x % ngrp) * 16 + wave * 4;
     const int rn = (n < n_keep) ? n : (n < n_keep + n_swap ? n + n_swap : n - n_swap);
     const float* xn = X + (int64_t)rn * HL * WL;
-    for (int e = tid; e < (HL + 2) * PC; e += 256) {
-        const int pr = e / PC, pc = e % PC, ih = pr - 1, iw = pc - 1;
-        xs[pr * PCP + pc] = (ih >= 0 && ih < HL && iw >= 0 && iw < WL) ? xn[ih * WL + iw] : 0.f;
+    // the sample's rows by 16-byte loads (all of a thread's in flight together), then the zero frame around them
+    for (int i = tid; i < HL * (WL / 4); i += 256) {
+        const int ih = i / (WL / 4), q = i % (WL / 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xn + ih * WL + 4 * q);
+        float* dst = xs + (ih + 1) * PCP + 1 + 4 * q;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
     }
+    for (int i = tid; i < PC; i += 256) { xs[i] = 0.f; xs[(HL + 1) * PCP + i] = 0.f; }
+    for (int i = tid; i < HL; i += 256) { xs[(i + 1) * PCP] = 0.f; xs[(i + 1) * PCP + PC - 1] = 0.f; }
     float acc[4][16];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
