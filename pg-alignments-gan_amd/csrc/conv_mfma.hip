@@ -815,10 +815,14 @@ __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restri
     const int csn = Cs / (int)gridDim.y, cs_lo = (int)blockIdx.y * csn;
     for (int i = tid; i < csn * 16; i += 256) ws[i] = W[cs_lo * 16 + i];
     const float* xn = X + (int64_t)n * HL * WL;
-    for (int e = tid; e < PR * PC; e += 256) {
-        const int pr = e / PC, pc = e % PC, ih = 2 * oh0 - 1 + pr, iw = pc - 1;
-        xs[e] = (ih >= 0 && ih < HL && iw >= 0 && iw < WL) ? xn[ih * WL + iw] : 0.f;
+    for (int i = tid; i < PR * (WL / 4); i += 256) {       // whole image rows by 16-byte loads, then the two halo columns
+        const int pr = i / (WL / 4), q = i % (WL / 4), ih = 2 * oh0 - 1 + pr;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ih >= 0 && ih < HL) v = *reinterpret_cast<const f32x4*>(xn + ih * WL + 4 * q);
+        float* dst = xs + pr * PC + 1 + 4 * q;
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
     }
+    for (int i = tid; i < PR * 2; i += 256) xs[(i >> 1) * PC + (i & 1) * (PC - 1)] = 0.f;
     __syncthreads();
     const int ohl = tid / WS, ow = tid % WS;
     float x[16];
