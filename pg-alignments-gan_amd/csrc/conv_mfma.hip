@@ -801,15 +801,16 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 // ------------------------------------------------------------------------------------------------
 // Cl == 1 stages (first discriminator conv / last generator conv-transpose): bandwidth-bound.
 // ------------------------------------------------------------------------------------------------
-// DOWN, Cl = 1: block = one sample x 8 output rows (256 pixels) x 1 / gridDim.y of the cs (small batches are split so
-// that every CU has several blocks' stores in flight); thread = pixel, loops over its cs.
+// DOWN, Cl = 1: block = one sample x 1024 output pixels (RT rows) x 1 / gridDim.y of the cs (small batches are split
+// so that every CU has several blocks' stores in flight); a thread takes four consecutive pixels of a row: their 4 x 10
+// inputs stay in registers, every cs costs four broadcast weight reads, 64 multiply-adds and one 16-byte store.
 template <int HS>
 __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                            float* __restrict__ Y, int N, int Cs) {
-    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 256 / WS;   // rows per block
-    constexpr int PR = 2 * RT + 2, PC = 2 * WS + 2;
+    constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 1024 / WS;   // rows per block
+    constexpr int PR = 2 * RT + 2, PC = 2 * WS + 4;                    // even row stride: 8-byte aligned pairs
     __shared__ __attribute__((aligned(16))) float ws[64 * 16];
-    __shared__ float xs[PR * PC];
+    __shared__ __attribute__((aligned(16))) float xs[PR * PC];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / (HS / RT), oh0 = (blockIdx.x % (HS / RT)) * RT;
     const int csn = Cs / (int)gridDim.y, cs_lo = (int)blockIdx.y * csn;
@@ -822,20 +823,31 @@ __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restri
         float* dst = xs + pr * PC + 1 + 4 * q;
         dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
     }
-    for (int i = tid; i < PR * 2; i += 256) xs[(i >> 1) * PC + (i & 1) * (PC - 1)] = 0.f;
+    for (int i = tid; i < PR * 2; i += 256) xs[(i >> 1) * PC + (i & 1) * (WL + 1)] = 0.f;
     __syncthreads();
-    const int ohl = tid / WS, ow = tid % WS;
-    float x[16];
+    const int ohl = tid / (WS / 4), ow0 = (tid % (WS / 4)) * 4;
+    float x[4][10];
 #pragma unroll
     for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) x[kh * 4 + kw] = xs[(2 * ohl + kh) * PC + 2 * ow + kw];
-    float* yn = Y + (((int64_t)n * Cs + cs_lo) * HS + oh0 + ohl) * WS + ow;
+        for (int i = 0; i < 5; ++i) {
+            const float2 v = *reinterpret_cast<const float2*>(xs + (2 * ohl + kh) * PC + 2 * ow0 + 2 * i);
+            x[kh][2 * i] = v.x;
+            x[kh][2 * i + 1] = v.y;
+        }
+    float* yn = Y + (((int64_t)n * Cs + cs_lo) * HS + oh0 + ohl) * WS + ow0;
     for (int cs = 0; cs < csn; ++cs) {
-        float s = 0.f;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(ws + cs * 16);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) s = fmaf(x[t], ws[cs * 16 + t], s);
-        yn[(int64_t)cs * HS * WS] = s;
+        for (int kh = 0; kh < 4; ++kh) {
+            const f32x4 wv = w4[kh];
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) o[px] = fmaf(x[kh][2 * px + kw], wv[kw], o[px]);
+        }
+        *reinterpret_cast<f32x4*>(yn + (int64_t)cs * HS * WS) = o;
     }
 }
 
@@ -1011,6 +1023,7 @@ __global__ __launch_bounds__(32 * RL) void rows_sum_kernel(const float* __restri
 // wave tiles (32 x 32 outputs each) a launch should reach before it stops splitting K: two per SIMD
 constexpr int FILL_WAVES = 2048;
 // tuning overrides (0 = choose from the launch size): see pgan_set_option
+int g_c1_gy = 0;       // tuning override "c1_gy": cs split of the single-channel DOWN kernel
 int g_down_kg = 0;     // 1, 2, 4: K groups of the DOWN kernel
 int g_down_ks = 0;     // 1, 2: K split across blocks of the DOWN kernel (2 partial sums added atomically)
 int g_down_variant = 0;  // experiment: 1 = 128x64 tile, 2 = 64x128, 3 = 128x128 (2 / 2 / 4 accumulators per wave)
@@ -1144,6 +1157,7 @@ int pgan_set_option(const char* name, int value) {
     if (eq(name, b) && value >= 0 && value <= 3) { g_up_mode = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_down_ks = value; return PGAN_OK; }
     if (eq(name, "down_variant") && value >= 0 && value <= 7) { g_down_variant = value; return PGAN_OK; }
+    if (eq(name, "c1_gy") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_c1_gy = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 
@@ -1152,9 +1166,14 @@ int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int 
     if (N <= 0) return PGAN_OK;
     if (Cl == 1) {
         if ((hs != 32 && hs != 64) || Cs > 64) return PGAN_EINVAL;
-        const int gy = (Cs % 4 == 0 && N * (hs == 32 ? 4 : 16) < 512) ? 4 : 1;      // 9.3 against 11.1 us at N = 64; no gain from 512 blocks on
-        if (hs == 32) conv_down_c1_kernel<32><<<dim3(N * (32 / 8), gy), 256, 0, st>>>(L, W, S, N, Cs);
-        else conv_down_c1_kernel<64><<<dim3(N * (64 / 4), gy), 256, 0, st>>>(L, W, S, N, Cs);
+        // blocks of 1024 pixels: one (hs = 32) or four (hs = 64) per sample; the cs are split until about two blocks per CU
+        const int per = hs == 32 ? 1 : 4;
+        int gy = 1;
+        while (gy < 8 && Cs % (2 * gy) == 0 && N * per * gy < 512) gy *= 2;
+        if (g_c1_gy) gy = g_c1_gy;
+        if (Cs % gy) return PGAN_EINVAL;
+        if (hs == 32) conv_down_c1_kernel<32><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs);
+        else conv_down_c1_kernel<64><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs);
         return pgan_launch_status();
     }
     switch (hs) {
