@@ -158,6 +158,47 @@ def test_kernels_write_only_their_slot_range(hip, N, lo, hi):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def test_kernels_beside_other_streams_equal_their_standalone_runs(hip):
+    """One gp critic step at batch 64 replayed from a launch tape (dense launches, both sample chains and the weight
+    gradients side by side): the stage-1 activations of the penalised and of the tangent slots, produced beside the other
+    chain's kernels, equal the same convolution run alone on the step's final inputs, bit for bit, and every
+    repetition reproduces the first one's gradients.  (Guards the build against packed-fp32 vector instructions:
+    with them the single-channel convolution returned wrong low halves of a register pair in one 16-lane row, only
+    while other kernels ran beside it.)"""
+    import pgan_tape
+    B = 64
+    eng, _, _ = make_engine(hip, B, "gp", "sigmoid", 31)
+    o = eng.ops
+    rs, rp = orc.synthetic_alignments(2 * B, 60)
+    eng.X0[:2 * B].copy_(rs.to(DEV))
+    eng.P0[:2 * B].copy_(rp.to(DEV))
+    eng.tbuf.copy_(torch.from_numpy(np.random.Generator(np.random.PCG64(62)).random(B)).float().to(DEV))
+    eng.critic_grads_resident(run_generator=False)
+    torch.cuda.synchronize()
+    pgan_tape.tape = entries = []
+    try:
+        eng.critic_grads_resident(run_generator=False)
+    finally:
+        pgan_tape.tape = None
+    torch.cuda.synchronize()
+    first = eng.D.gflat.clone()
+    tmp = torch.empty_like(eng.dA[1][:B])
+    NS, NT = eng.NS, eng.NT
+    for rep in range(12):
+        for k in range(1, eng.nS + 1):       # what the step itself fills starts as NaN
+            eng.dA[k][2 * B:].fill_(float("nan"))
+            eng.dH[k][2 * B:].fill_(float("nan"))
+        eng.X0[2 * B:].fill_(float("nan"))
+        torch.cuda.synchronize()
+        pgan_tape.replay(entries)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.D.gflat, first), rep
+        for lo, hi in ((2 * B, NS), (NS, NT)):
+            o.conv_down(eng.X0[lo:hi], eng.dconv_w(1), tmp)
+            torch.cuda.synchronize()
+            assert torch.equal(tmp, eng.dA[1][lo:hi]), (rep, lo, int((tmp != eng.dA[1][lo:hi]).sum()))
+
+
 def _trainer(hip, B, loss="gp", critic_iter=2, seed=77, **kw):
     from pgan_trainer import FusedTrainer
     tr = FusedTrainer(hip, B, torch.device(DEV), loss=loss, critic_iter=critic_iter, seed=seed, **kw)

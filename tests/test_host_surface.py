@@ -25,6 +25,28 @@ def test_library_exports_every_declared_symbol():
     assert sorted(pgan_hip.EXPORTS) == declared
 
 
+def test_library_holds_no_packed_fp32_instructions(tmp_path):
+    """Device code is built without the packed-fp32 vector instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32):
+    kernels that held them returned wrong low halves of a register pair in one 16-lane row while kernels of other
+    streams ran beside them.  Disassembles every gfx950 code object of the shipped library."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    so = shutil.copy(os.path.join(ROOT, "pg-alignments-gan_amd", "libpgan_hip.so"), tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(objs) >= 8, objs
+    kernels = 0
+    for f in objs:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        kernels += asm.count("s_endpgm")
+        hits = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
+        assert not hits, f"{f}: {len(hits)} packed-fp32 instructions"
+    assert kernels >= 50
+
+
 def test_module_state_dict_layout_matches_reference_tables():
     import layers
     g = layers.DC_Generator_Leaky_Sig(64, 128, 0.1, 1, 4)
