@@ -265,6 +265,9 @@ class Engine:
         # later (two half-size passes per stage instead of one): the first half leaves the weight-gradient stream early,
         # beside the penalty chain (7.26 -> 7.10 ms per iteration; PGAN_SPLIT_WGRAD=0: one pass over all slots)
         self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "1") != "0"
+        # loss / norm-gradient / head-gradient launches of a critic step beside its last weight-gradient passes
+        # (PGAN_TAIL_BESIDE_WGRAD=0: after them, for comparison)
+        self.tail_beside_wgrad = os.environ.get("PGAN_TAIL_BESIDE_WGRAD", "1") != "0"
         self._bn_parts = {}
         # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
         # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
@@ -731,6 +734,7 @@ class Engine:
                 self.side.wait_mark()
                 o.head_fwd(self.dH[nS][:2 * B], self.F1, Dp["out.weight"], Dp["out.bias"], self.score)
                 self._d_backward1(0, 2 * B, 0, 0, None)
+                self.wside.set_mark()       # scores, adjoints and per-sample norm gradients of the Wasserstein samples
                 for k in (range(nS, 0, -1) if self.split_wgrad else ()):
                     o.conv_wgrad(self.dJ[k][:2 * B], self.dH[k - 1][:2 * B], Dg[f"twod_conv_layers.{3 * (k - 1)}.weight"],
                                  bound_s=self.dJmax[k][:2 * B], bound_l=self._hmax(k - 1, 0, 2 * B))
@@ -784,13 +788,20 @@ class Engine:
             if k > 1:
                 o.conv_up(self.dJ[k][NS:NT], self.dconv_w(k), self.dU[k - 1][NS:NT], bound=self.dJmax[k][NS:NT])
                 hbar = self.dU[k - 1][NS:NT]
-        self.wside.join()
-        if two_chains and hasattr(o, "release_weights"):
-            o.release_weights()
+        # The loss value, the norm layers' parameter gradients and the head's weight gradient need the chains' adjoints
+        # but none of the convolution weight gradients: they run here beside the last weight-gradient passes (the
+        # single-channel stage's comes last) instead of after them.
+        if not self.tail_beside_wgrad:
+            self.wside.join()
+        elif two_chains:
+            self.wside.wait_mark()
         o.critic_loss(self.score, B, self.pen, self.closs)
         r = (0, 2 * B, NS, NT) if self.loss == "gp" else (NS, NT, 0, 0)
         self._reduce_norm_grads(*r)
         o.head_wgrad(self.dH[nS], self.coef_head, Dg["out.weight"].view(-1)[:FEAT2])
+        self.wside.join()
+        if two_chains and hasattr(o, "release_weights"):
+            o.release_weights()
         self.side.join()
 
     def critic_step(self, real_s, real_p, z, t=None) -> None:

@@ -14,6 +14,7 @@ statistics over all ranks' samples (per-channel partial sums all-reduced inside 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -278,7 +279,9 @@ class FusedTrainer:
         with gs:
             o.philox(e.Zw[:B], self.rng_z, True)
             e.gen_forward_chunks(0, 1)
-        for i in range(n):
+
+        def step_inputs(i):
+            """Critic step i's real batch, interpolation draws and fakes into the discriminator's input slots."""
             o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
             if e.loss == "gp":
                 o.philox(e.tbuf, self.rng_t, False)
@@ -287,6 +290,14 @@ class FusedTrainer:
             elif i == 1 and self.gen_done:
                 pgan_tape.call(torch.cuda.current_stream().wait_event, self.gen_done)
             self._hand_fakes(e.fake_s[i * B:(i + 1) * B], e.fake_p[i * B:(i + 1) * B])
+
+        # A critic step ends in a serial run of small launches (gradient reductions, Adam, weight preparation) and used to
+        # begin with another (batch gather, cursor, draws, fake copies): six launches that depend on nothing the optimizer
+        # writes.  They are enqueued on the 1-D towers' stream right after the previous step's kernels have been joined,
+        # beside that step's Adam update, and joined before the next step starts.
+        ahead = os.environ.get("PGAN_INPUTS_AHEAD", "1") != "0"
+        step_inputs(0)
+        for i in range(n):
             if i == 0:
                 gs.fork()
                 with gs:
@@ -295,8 +306,17 @@ class FusedTrainer:
                     if self.gen_done:
                         pgan_tape.call(self.gen_done.record, gs.stream)
             e.critic_grads_resident(run_generator=False)
+            if ahead and i + 1 < n:
+                e.side.fork()
+                with e.side:
+                    step_inputs(i + 1)
             self._reduce(e.D.gflat)
             e.adam_d()
+            if i + 1 < n:
+                if ahead:
+                    e.side.join()
+                else:
+                    step_inputs(i + 1)
         gs.join()
         e.generator_grads_resident(forward_done=True)
         self._reduce(e.G.gflat)
