@@ -118,6 +118,7 @@ class RecordingOps:
 
     DESCRIBE = {
         "conv_down": _conv.__func__("conv_down"), "conv_up": _conv.__func__("conv_up"),
+        "conv_down_gn_sums": _conv.__func__("conv_down"),      # first stage: counted (and timed) as the convolution it is
         "conv_wgrad": _conv.__func__("conv_wgrad"),
         # the GroupNorm backward ops recompute the LeakyReLU mask from the pre-norm input: the forward output is not read
         "gn_fwd": _stream_op.__func__("gn_fwd", 2), "gn_bwd": _stream_op.__func__("gn_bwd", 3),

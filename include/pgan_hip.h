@@ -31,6 +31,12 @@ int pgan_set_option(const char* name, int value);
 /* S = conv2d(L, W, stride 2, pad 1): nn.Conv2d forward, src/layers.py:441-463 (discriminator);
  * input-gradient of nn.ConvTranspose2d, src/layers.py:97-112 (generator backward). */
 int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st);
+/* The same for the discriminator's first stage (Cl == 1, hs == 32, Cs == 64; src/layers.py:441) with the statistics pass
+ * of the GroupNorm that follows it (:442) folded in: the kernel also leaves the [N][8][2] slice partial sums (sum, sum of
+ * squares; doubles) of S in gn_ws, the workspace of the pgan_gn_fwd_presummed call that must follow on the same stream.
+ * Any other shape returns -1 and launches nothing. */
+int pgan_conv_down_gn_sums(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, void* gn_ws,
+                           long long gn_ws_bytes, hipStream_t st);
 
 /* L = conv_transpose2d(S, W, stride 2, pad 1): nn.ConvTranspose2d forward, src/layers.py:97-112, with
  * the trailing nn.Sigmoid (:114) / nn.Tanh (:255) fused when act = 1 / 2 (Cl == 1 only);
@@ -125,6 +131,9 @@ int pgan_rows_reduce_multi(const float* const* part, const int* ld, float* const
 long long pgan_gn_workspace_bytes(int N);
 int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h, float* stats, void* ws,
                 long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
+/* pgan_gn_fwd whose slice partial sums are already in ws (written by pgan_conv_down_gn_sums): the apply launch only. */
+int pgan_gn_fwd_presummed(const float* a, const float* gamma, const float* beta, float* h, float* stats, const void* ws,
+                          long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* pgan_gn_fwd for callers that cannot allocate device memory or bring a workspace (code under hipGraph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result as pgan_gn_fwd; the
  * slice partial sums live in a fixed array inside the library (384 KiB per GPU, for up to

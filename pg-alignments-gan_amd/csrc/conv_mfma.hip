@@ -804,9 +804,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 // DOWN, Cl = 1: block = one sample x 1024 output pixels (RT rows) x 1 / gridDim.y of the cs (small batches are split
 // so that every CU has several blocks' stores in flight); a thread takes four consecutive pixels of a row: their 4 x 10
 // inputs stay in registers, every cs costs four broadcast weight reads, 64 multiply-adds and one 16-byte store.
-template <int HS>
+// STATS: the block also leaves the sum and the sum of squares of its outputs in gn_ws[(n * gridDim.y + blockIdx.y) * 2 ..]
+// -- with one block per sample and eight channel groups (hs = 32, gridDim.y = 8) these are the eight slice partial sums
+// per sample that the GroupNorm forward's apply launch reads (norm.hip), so the layer's separate sums launch and its
+// pass over the activation are not needed.
+template <int HS, bool STATS>
 __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                           float* __restrict__ Y, int N, int Cs) {
+                                                           float* __restrict__ Y, int N, int Cs, double* __restrict__ gn_ws) {
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS, RT = 1024 / WS;   // rows per block
     constexpr int PR = 2 * RT + 2, PC = 2 * WS + 4;                    // even row stride: 8-byte aligned pairs
     __shared__ __attribute__((aligned(16))) float ws[64 * 16];
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restri
             x[kh][2 * i + 1] = v.y;
         }
     float* yn = Y + (((int64_t)n * Cs + cs_lo) * HS + oh0 + ohl) * WS + ow0;
+    float s1 = 0.f, s2 = 0.f;
     for (int cs = 0; cs < csn; ++cs) {
         const f32x4* w4 = reinterpret_cast<const f32x4*>(ws + cs * 16);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -848,6 +853,26 @@ __global__ __launch_bounds__(256) void conv_down_c1_kernel(const float* __restri
                 for (int kw = 0; kw < 4; ++kw) o[px] = fmaf(x[kh][2 * px + kw], wv[kw], o[px]);
         }
         *reinterpret_cast<f32x4*>(yn + (int64_t)cs * HS * WS) = o;
+        if constexpr (STATS) {
+            s1 += (o[0] + o[1]) + (o[2] + o[3]);
+            s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        }
+    }
+    if constexpr (STATS) {       // fixed order: lanes by xor distance, then the four waves in turn
+        __shared__ double red[4][2];
+        double d1 = s1, d2 = s2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d1 += __shfl_xor(d1, o, 64);
+            d2 += __shfl_xor(d2, o, 64);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6][0] = d1; red[tid >> 6][1] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            double* dst = gn_ws + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 2;
+            dst[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            dst[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        }
     }
 }
 
@@ -1161,6 +1186,17 @@ int pgan_set_option(const char* name, int value) {
     return PGAN_EINVAL;
 }
 
+// pgan_conv_down for the discriminator's first stage (Cl = 1, hs = 32, Cs = 64) that also leaves the GroupNorm slice
+// partial sums of its output in gn_ws (the layout pgan_gn_fwd's apply launch reads: [N][8][2] doubles): follow it with
+// pgan_gn_fwd_presummed on the same stream and workspace.  Other shapes: PGAN_EINVAL, nothing launched.
+int pgan_conv_down_gn_sums(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, void* gn_ws,
+                           long long gn_ws_bytes, hipStream_t st) {
+    if (N <= 0) return PGAN_OK;
+    if (Cl != 1 || hs != 32 || Cs != 64 || !gn_ws || gn_ws_bytes < (long long)N * 8 * 2 * 8) return PGAN_EINVAL;
+    conv_down_c1_kernel<32, true><<<dim3(N, 8), 256, 0, st>>>(L, W, S, N, Cs, static_cast<double*>(gn_ws));
+    return pgan_launch_status();
+}
+
 // S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W[Cs,Cl,4,4], stride 2, pad 1).  H = hs.
 int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int Cl, int hs, hipStream_t st) {
     if (N <= 0) return PGAN_OK;
@@ -1172,8 +1208,8 @@ int pgan_conv_down(const float* L, const float* W, float* S, int N, int Cs, int 
         while (gy < 8 && Cs % (2 * gy) == 0 && N * per * gy < 512) gy *= 2;
         if (g_c1_gy) gy = g_c1_gy;
         if (Cs % gy) return PGAN_EINVAL;
-        if (hs == 32) conv_down_c1_kernel<32><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs);
-        else conv_down_c1_kernel<64><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs);
+        if (hs == 32) conv_down_c1_kernel<32, false><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs, nullptr);
+        else conv_down_c1_kernel<64, false><<<dim3(N * per, gy), 256, 0, st>>>(L, W, S, N, Cs, nullptr);
         return pgan_launch_status();
     }
     switch (hs) {

@@ -672,6 +672,16 @@ int pgan_gn_fwd(const float* a, const float* gamma, const float* beta, float* h,
     return pgan_launch_status();
 }
 
+// pgan_gn_fwd without its sums launch: ws already holds the slice partial sums ([N][8][2] doubles: sum and sum of
+// squares of each eighth of every sample), left there by the producer of a on the same stream
+// (pgan_conv_down_gn_sums).
+int pgan_gn_fwd_presummed(const float* a, const float* gamma, const float* beta, float* h, float* stats, const void* ws,
+                          long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
+    if (!gn_shape_ok(N, C, HW, ws, ws_bytes)) return PGAN_EINVAL;
+    gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, static_cast<const double*>(ws), C * HW, HW, C, amax);
+    return pgan_launch_status();
+}
+
 // The same operation for callers that cannot allocate (code under graph capture, serving loops, harnesses that forbid
 // hipMalloc): the slice partial sums live in `scratch`, a fixed array inside the library's code object, instead of a
 // caller workspace.  Each GPU holds its own copy of the array at its own address: the address is looked up once per

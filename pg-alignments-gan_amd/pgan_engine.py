@@ -611,9 +611,15 @@ class Engine:
 
     def _d_forward2d(self, lo: int, hi: int) -> None:
         o = self.ops
+        fused = getattr(o, "conv_down_gn_sums", None)      # first stage: the norm's statistics pass inside the convolution
         for k in range(1, self.nS + 1):
-            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi], bound=self._hmax(k - 1, lo, hi))
             gw, gb = self.dgn(k)
+            if k == 1 and fused is not None:
+                pre = fused(self.dH[0][lo:hi], self.dconv_w(1), self.dA[1][lo:hi])
+                o.gn_fwd(self.dA[1][lo:hi], gw, gb, self.dH[1][lo:hi], self.dStat[1][lo:hi], amax=self.dHmax[1][lo:hi],
+                         **({"presummed": True} if pre else {}))
+                continue
+            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi], bound=self._hmax(k - 1, lo, hi))
             o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi], amax=self.dHmax[k][lo:hi])
 
     def _d_backward1(self, lo: int, hi: int, g_lo: int, g_hi: int, g_out: Optional[torch.Tensor]) -> None:

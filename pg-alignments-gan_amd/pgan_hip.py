@@ -34,6 +34,7 @@ _lib = _load()
 P, I, L, F = c_void_p, c_int, c_longlong, c_float
 _SIGS = {
     "pgan_conv_down": [P, P, P, I, I, I, I, P],
+    "pgan_conv_down_gn_sums": [P, P, P, I, I, I, I, P, L, P],
     "pgan_conv_up": [P, P, P, I, I, I, I, I, P],
     "pgan_conv_wgrad": [P, P, P, P, L, I, I, I, I, I, I, I, P],
     "pgan_conv_x3_prep": [P, P, I, I, P],
@@ -48,6 +49,7 @@ _SIGS = {
     "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
     "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P, P],
+    "pgan_gn_fwd_presummed": [P, P, P, P, P, P, L, I, I, I, P, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
     "pgan_gn_jvp": [P, P, P, P, P, P, P, P, P, L, I, I, I, P, P],
@@ -367,6 +369,24 @@ class HipOps:
             return
         _check(_lib.pgan_conv_down(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, _stream()), "pgan_conv_down")
 
+    # the discriminator's first stage: convolution that leaves the following GroupNorm's slice sums in this stream's norm
+    # scratch (PGAN_FUSE_STAGE1=0: separate sums launch, for comparison)
+    fuse_stage1 = os.environ.get("PGAN_FUSE_STAGE1", "1") != "0"
+
+    def conv_down_gn_sums(self, x, w, y) -> bool:
+        """conv_down that also leaves the GroupNorm slice partial sums of y in the current stream's norm scratch, where the
+        shape allows (then returns True: follow it with gn_fwd(..., presummed=True) on this stream); plain conv_down and
+        False otherwise."""
+        N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
+        Cs, hs = w.shape[0], HL // 2
+        if not (self.fuse_stage1 and Cl == 1 and hs == 32 and Cs == 64):
+            self.conv_down(x, w, y)
+            return False
+        assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
+        _check(_lib.pgan_conv_down_gn_sums(_ptr(x), _ptr(w), _ptr(y), N, Cs, Cl, hs, *self._gnws(), _stream()),
+               "pgan_conv_down_gn_sums")
+        return True
+
     def conv_up(self, y, w, x, act=0, bound=None):
         N, Cs, hs = y.shape[0], y.shape[1], y.shape[2]
         Cl = w.shape[1]
@@ -475,10 +495,16 @@ class HipOps:
     def release_weights(self) -> None:
         self._hold = False
 
-    def gn_fwd(self, a, gamma, beta, h, stats, amax=None):
+    def gn_fwd(self, a, gamma, beta, h, stats, amax=None, presummed=False):
         """amax (every GroupNorm op): optional [N, GN_AMAX_SLOTS] output, the largest magnitude of each of the eight
-        slices of every sample of the op's main output -- what conv_* take as `bound`."""
+        slices of every sample of the op's main output -- what conv_* take as `bound`.
+        presummed: the slice sums are already in this stream's norm scratch (conv_down_gn_sums returned True)."""
         N, C = a.shape[0], a.shape[1]
+        if presummed:
+            _check(_lib.pgan_gn_fwd_presummed(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C,
+                                              _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()),
+                   "pgan_gn_fwd_presummed")
+            return
         _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_fwd")
 

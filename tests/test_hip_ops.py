@@ -364,6 +364,36 @@ def test_conv_c1(hip, N, act, Cs, hs):
     close("conv_wgrad_c1", got, want)
 
 
+@pytest.mark.parametrize("N", [1, 3, 64, 130])
+def test_first_stage_conv_with_groupnorm_sums(hip, N):
+    """Discriminator stage 1 (src/layers.py:441-443): the convolution that leaves the following GroupNorm's slice sums in
+    the stream's norm scratch, then the norm's apply launch alone -- against the fp64 statement of conv -> GroupNorm ->
+    LeakyReLU, and the convolution output bit for bit against the plain kernel's."""
+    rng = np.random.default_rng(40 + N)
+    x, w = rnd(rng, N, 1, 64, 64), rnd(rng, 64, 1, 4, 4, scale=0.2)
+    gamma, beta = 1 + 0.2 * rnd(rng, 64), 0.2 * rnd(rng, 64)
+    a_w = torch.zeros(N, 64, 32, 32, dtype=torch.float64)
+    REF.conv_down(*d64(x, w), a_w)
+    h_w, st_w = torch.zeros_like(a_w), torch.zeros(N, 2, dtype=torch.float64)
+    REF.gn_fwd(a_w, *d64(gamma, beta), h_w, st_w)
+    nan = lambda *sh: torch.full(sh, float("nan"), device=DEV)
+    a_g, a_plain, h_g, st_g, am = nan(N, 64, 32, 32), nan(N, 64, 32, 32), nan(N, 64, 32, 32), nan(N, 2), nan(N, 8)
+    xg, wg = gpu(x, w)
+    assert hip.conv_down_gn_sums(xg, wg, a_g) is True
+    hip.gn_fwd(a_g, *gpu(gamma, beta), h_g, st_g, amax=am, presummed=True)
+    hip.conv_down(xg, wg, a_plain)
+    torch.cuda.synchronize()
+    assert torch.equal(a_g, a_plain)
+    close("conv_down_gn_sums.a", a_g, a_w)
+    close("gn_fwd_presummed.h", h_g, h_w)
+    close("gn_fwd_presummed.stats", st_g, st_w)
+    assert torch.equal(am.amax(1), h_g.abs().flatten(1).amax(1))
+    # shapes the fused kernel does not take fall back to the plain convolution
+    x2, w2 = gpu(rnd(rng, 2, 1, 128, 128), rnd(rng, 32, 1, 4, 4, scale=0.2))
+    a2 = nan(2, 32, 64, 64)
+    assert hip.conv_down_gn_sums(x2, w2, a2) is False and not torch.isnan(a2).any()
+
+
 GN_SHAPES = [(64, 32), (128, 16), (256, 8), (512, 4), (32, 64)]
 
 
