@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on one box: bench config 1 with the shipped library (no packed-fp32 instructions) and with tools/libpgan_hip_pk.so
-# (same sources built with PGAN_PACKED_FP32=1 into another file; not tracked), alternating twice.
+# (same sources built with packed-fp32 instructions allowed -- PGAN_PACKED_FP32=1 python __graft_entry__.py --force, the
+# result copied there, then the default build restored; not tracked), alternating twice.
 L=pg-alignments-gan_amd/libpgan_hip.so
 cp $L /tmp/lib_nopk.so
 for round in 1 2; do
