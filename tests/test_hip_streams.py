@@ -210,6 +210,34 @@ def _trainer(hip, B, loss="gp", critic_iter=2, seed=77, **kw):
     return tr
 
 
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_step_boundary_overlap_does_not_change_results(loss, monkeypatch):
+    """The next critic step's input launches beside Adam (PGAN_INPUTS_AHEAD) and the loss / norm-gradient / head-gradient
+    launches beside the last weight-gradient passes (PGAN_TAIL_BESIDE_WGRAD) only move launches between streams: with
+    both switched off the weights, Adam moments, running statistics, losses, pool cursor and generator state after
+    several tape-replayed iterations are the same bits."""
+    from pgan_hip import HipOps
+    ops = HipOps(torch.device(DEV))      # its own backend: the trainers' streams would use up the shared one's stream pool
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PGAN_INPUTS_AHEAD", mode)
+        monkeypatch.setenv("PGAN_TAIL_BESIDE_WGRAD", mode)
+        tr = _trainer(ops, 8, loss=loss, critic_iter=3)
+        assert tr.eng.tail_beside_wgrad == (mode == "1")
+        tr.use_tape = True
+        for _ in range(5):
+            tr.step()
+        torch.cuda.synchronize()
+        e = tr.eng
+        out[mode] = dict(d=e.D.flat.clone(), dm=e.D.mflat.clone(), dv=e.D.vflat.clone(), g=e.G.flat.clone(),
+                         gm=e.G.mflat.clone(), run=e.Gbuf.p["twod_conv_layers.1.running_var"].clone(),
+                         rz=tr.rng_z.clone(), rt=tr.rng_t.clone(), cur=tr.cursor.clone())
+        out[mode + "l"] = tr.losses()
+    assert tuple(out["1l"]) == tuple(out["0l"])
+    for k in out["1"]:
+        assert torch.equal(out["1"][k], out["0"][k]), (k, float((out["1"][k].float() - out["0"][k].float()).abs().max()))
+
+
 def test_capture_allocates_nothing_and_refuses_unreserved_streams(hip):
     """Graph capture: the allocator's request count does not move between begin and end (capture() checks it), the op
     backend is back out of capture mode afterwards, and a launch on a stream whose scratch was never reserved is an
