@@ -471,14 +471,28 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     }
 }
 
+// ds_read_b128 serves a wave in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --
+// over 64 banks: a group is conflict-free when its sixteen 16-byte reads fall into sixteen different 16-byte slots of a
+// 256-byte LDS row.  The 32 columns of an MFMA B tile are therefore handed to the tile's pixels group by group: the
+// first group's lanes take pixels 0-15 of the tile, the second group's pixels 16-31.
+__device__ __forceinline__ int lds_group_pixel(int j) {
+    return j < 4 ? j : (j < 12 ? j + 12 : (j < 16 ? j - 8 : (j < 20 ? j + 8 : (j < 28 ? j - 12 : j))));
+}
+
 // ------------------------------------------------------------------------------------------------
 // UP: the four sub-pixel phases of a tile go to four waves; NC such groups (different 32-cl row tiles)
 // share the block's S patch.  A phase is a 2x2 stride-1 convolution, evaluated tap by tap with
 // K = 16 cs per MFMA; a wave keeps the weight fragments of its four taps in registers and refills each
 // for the next K step right after using it.  LDS holds the S patch channel-innermost
-// [plane][patch pixel][16 cs], double-buffered, one barrier per K step; the two 16-byte halves of a
-// 32-byte pixel row are swapped on every other group of four pixels so that the eight lanes of a b128
-// access phase hit distinct banks.
+// [plane][patch pixel][16 cs], double-buffered, one barrier per K step.  A pixel's 32 bytes are two 16-byte slots.  The
+// sixteen pixels one lane group reads cover every slot pair of a 256-byte LDS row exactly twice: at hs = 16 with columns
+// in pixel order (a group is 8 + 8 pixels of two rows), at hs = 8 / 4 once the columns are handed out group by group
+// (lds_group_pixel: a group is two rows / one whole sample) -- both times the two pixels of a pair lie in rows of
+// different parity; at hs = 32 (a group is 16 pixels of one row) they lie an odd multiple of eight columns apart.  The
+// two halves are swapped by that bit (up_swz), so a group's reads hit sixteen different slots.  Counters before, with a
+// swap every four pixels (which suits 8-lane groups on 32 banks): 43 % of the LDS cycles at hs = 16 and 68 % at hs = 4
+// were bank-conflict cycles; now none.  (Pixel order is kept at hs >= 16, where the output stores dominate: with the
+// group-wise order every 16-lane store chunk touched two rows and the kernel lost 6 %.)
 // Tap kh feeds output-row phase PH[kh] from S row a + DH[kh]:  kh 0:(1,+1) 1:(0,0) 2:(1,0) 3:(0,-1).
 // ------------------------------------------------------------------------------------------------
 template <int HS, int BN, int NC>
@@ -496,6 +510,9 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
+    // the pixel of the tile that column j of the MFMA tile stands for, and the bit that swaps a pixel's two LDS slots
+    const int jp = WS >= 16 ? j : lds_group_pixel(j);
+    auto up_swz = [](int prow, int pcol) { return (WS >= 32 ? (pcol >> 3) : prow) & 1; };
     const int nmt = Cl / BM, npt = T::ntiles(N);
     const int b = xcd_remap(blockIdx.x, nmt * npt);
     // Each XCD gets a contiguous run of b.  cl_major: a run is one row tile (its weights stay in that XCD's L2)
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         const int n = n0 + seg, a = oh0 - 1 + pr, bb = pc - 1;
         bval[q] = (e < NI) && n < N && a >= 0 && a < HS && bb >= 0 && bb < WS;
         boff[q] = bval[q] ? (uint32_t)(((n * Cs + oct * 8) * HS + a) * WS + bb) : 0u;
-        blds[q] = (e < NI) ? p * 8 + ((oct ^ (p >> 2)) & 1) * 4 : -1;
+        blds[q] = (e < NI) ? p * 8 + ((oct ^ up_swz(seg * PR + pr, pc)) & 1) * 4 : -1;
     }
     float breg[NQ][8];
     float sx = 1.f;        // fp16 split: the block's activations are staged times this power of two (2^-ex)
@@ -563,10 +580,10 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
             aofs[th * 2 + tw] = (uint32_t)(((kh * 4 + kw) * (Cs / 16) * Cl + cl0 + j) * 16 + 8 * h);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const int pt = tn * 32 + j;
+                const int pt = tn * 32 + jp;
                 const int seg = pt / (R * WS), rem = pt % (R * WS), al = rem / WS, bl = rem % WS;
-                const int p = (seg * PR + al + 1 + dh) * PC + bl + 1 + dw;
-                bofs[th * 2 + tw][tn] = p * 8 + ((h ^ (p >> 2)) & 1) * 4;
+                const int prow = seg * PR + al + 1 + dh, pcol = bl + 1 + dw;
+                bofs[th * 2 + tw][tn] = (prow * PC + pcol) * 8 + ((h ^ up_swz(prow, pcol)) & 1) * 4;
             }
         }
     f32x16 acc[TN], acl[TN];
@@ -625,7 +642,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int pt = tn * 32 + j;
+        const int pt = tn * 32 + jp;
         const int seg = pt / (R * WS), rem = pt % (R * WS), al = rem / WS, bl = rem % WS;
         const int n = n0 + seg;
         if (n >= N) continue;
