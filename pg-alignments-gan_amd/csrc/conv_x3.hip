@@ -594,11 +594,17 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 
     // gridDim.y > 1: the cs range is split across blocks, which then add into a zeroed X
     const int nk = Cs / (16 * (int)gridDim.y), k0 = blockIdx.y * nk;
-    u32x4 a[4][NPL];
-    auto aload = [&](int t, int ks) {                 // weight fragments of tap t, K step ks
+    // Weight fragments are loaded PD K steps ahead of their use.  With 32-pixel tiles a K step is 12 MFMAs per wave
+    // (about 400 cycles) at one or two waves per SIMD -- less than an L2 round trip under load, and the waves sat parked
+    // on s_waitcnt vmcnt for half of their cycles (hs = 4: 49-59 % by the SQ counters); two register sets, used in turn,
+    // double the cover for 32 more registers.  The wider tiles run 24-48 MFMAs per K step and have no registers to spare.
+    constexpr int PD = (BN == 32) ? 2 : 1;
+    u32x4 a[PD][4][NPL];
+    auto aload = [&](auto d, int t, int ks) {         // weight fragments of tap t, K step ks, into register set d
+        constexpr int D = decltype(d)::value;
         const uint16_t* Wk = WP + (size_t)ks * Cl * 16;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) a[t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
+        for (int i = 0; i < NPL; ++i) a[D][t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
     };
     if constexpr (F16) {       // one pass over this block's patches for their largest magnitude -> the block's scale
         float m = 0.f;
@@ -614,29 +620,37 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         sx = pow2f(-ex);
     }
     gload(k0 * 16);
+    static_for<PD>([&](auto d) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) aload(t, k0);
+        for (int t = 0; t < 4; ++t) aload(d, t, k0 + min((int)decltype(d)::value, nk - 1));
+    });
     lstore(lds);
     if (nk > 1) gload((k0 + 1) * 16);
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const uint32_t* Bs = lds + (kc & 1) * NPL * BPL;
-        uint32_t* Bn = lds + ((kc + 1) & 1) * NPL * BPL;
-        const int knext = k0 + min(kc + 1, nk - 1);
+    for (int kb = 0; kb < nk; kb += PD) {
+        static_for<PD>([&](auto d) {
+            constexpr int D = decltype(d)::value;
+            const int kc = kb + D;
+            if (kc < nk) {                                    // uniform over the block
+                const uint32_t* Bs = lds + (kc & 1) * NPL * BPL;
+                uint32_t* Bn = lds + ((kc + 1) & 1) * NPL * BPL;
+                const int knext = k0 + min(kc + PD, nk - 1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            u32x4 bo[TN][NPL];
+                for (int t = 0; t < 4; ++t) {
+                    u32x4 bo[TN][NPL];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+                    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int i = 0; i < NPL; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
+                        for (int i = 0; i < NPL; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) mfma_x3(a[t], bo[tn], acc[tn], acl[tn]);
-            aload(t, knext);
-            if (t == 0 && kc + 1 < nk) lstore(Bn);                       // K step kc+1: registers -> other buffer
-            if (t == 1 && kc + 2 < nk) gload((k0 + kc + 2) * 16);        // K step kc+2: global -> registers
-        }
-        __syncthreads();
+                    for (int tn = 0; tn < TN; ++tn) mfma_x3(a[D][t], bo[tn], acc[tn], acl[tn]);
+                    aload(d, t, knext);
+                    if (t == 0 && kc + 1 < nk) lstore(Bn);                       // K step kc+1: registers -> other buffer
+                    if (t == 1 && kc + 2 < nk) gload((k0 + kc + 2) * 16);        // K step kc+2: global -> registers
+                }
+                __syncthreads();
+            }
+        });
     }
 
     const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
