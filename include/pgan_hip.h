@@ -106,6 +106,8 @@ int pgan_x3_set_option(const char* name, int value);
  * L follow L's own sample order (the call applies r(n) to them). */
 long long pgan_conv_h2_prep_bytes(int Cs, int Cl);
 int pgan_conv_h2_prep(const float* W, void* planes, int Cs, int Cl, hipStream_t st);
+/* zeroes the header of a planes buffer on st (the running maximum starts again at the next preparation) */
+int pgan_conv_h2_forget(void* planes, hipStream_t st);
 int pgan_conv_h2_prep_multi(const float* const* W, void* const* planes, const int* Cs, const int* Cl, int n,
                             hipStream_t st);      /* n <= 6 tensors in two launches */
 int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
@@ -218,19 +220,46 @@ int pgan_act_bwd(const float* dy, const float* y, float* dx, long long n, int ac
 int pgan_affine(const float* x, float* out, long long n, float scale, float shift, hipStream_t st);
 
 /* torch.optim.Adam step (src/train_wgan_v2.py:489-490,612,634) over one flat, 4-float-padded buffer.
- * step_dev != NULL: device-resident step counter, incremented then used (graph replay advances it). */
+ * step_dev != NULL: device-resident step counter, incremented then used (graph replay advances it).
+ * grad_scale multiplies g as it is read: 1 / ranks when g holds the sum of a data-parallel run's gradients (the mean
+ * of src/train_wgan_v2.py:584-585 over the global batch), 1 otherwise. */
 int pgan_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-              int* step_dev, int step, hipStream_t st);
+              float grad_scale, int* step_dev, int step, hipStream_t st);
 
 /* Philox4x32-10 draws replacing torch.randn (src/train_wgan_v2.py:534,621) and np.random.random
  * (src/layers.py:37).  state: 4 uint32 on the device (seed lo, hi, offset lo, hi), advanced by the call. */
 int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStream_t st);
+/* values [skip, skip + n) of a draw of `total` values; the state advances by the whole draw.  The ranks of a
+ * data-parallel run that keep one generator state in step each take their rows of the global batch's draw this way
+ * (rows [r B/P, (r+1) B/P) of z and t), so that P ranks draw what one device at the global batch would. */
+int pgan_philox_slice(float* out, long long n, long long skip, long long total, unsigned int* state, int normal,
+                      hipStream_t st);
 
 /* Next B alignments (sites [.,1,64,64] = Ms floats, positions [.,1,64] = Mp floats) of a pool that is
  * resident in HBM, wrapping at npool; the cursor is a device int advanced by the call.  Replaces the
  * host loader's get_batch + .to(device) (src/train_wgan_v2.py:517,526-527) inside a captured step. */
 int pgan_take_batch(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool, int B,
                     int Ms, int Mp, hipStream_t st);
+/* the B alignments from cursor + offset on, cursor advanced by `advance`: a rank's rows of the global batch */
+int pgan_take_batch_slice(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool,
+                          int B, int Ms, int Mp, int offset, int advance, hipStream_t st);
+
+/* ---- per-batch augmentations of the real alignments, drawn on the device inside the step (Philox state as
+ * pgan_philox).  pgan_label_smooth: sites <- sites (1 - ey) + centre ey, ey ~ U(0, noise) per element
+ * (DataGeneratorDisk.get_batch(label_smooth=True), src/train_wgan_v2.py:265-268: noise = centre = 0.05); normalized != 0:
+ * sites hold (raw - 0.5) / 0.5 and the raw values are smoothed (the reference smooths before Normalize, :519-521).
+ * ey_given: NULL, or the n draws to use (tests).  The n values are values [skip, skip + n) of a draw of `total` (a rank's
+ * rows of the global batch); n and skip multiples of 4.
+ * pgan_mono_switch: switch_monomorphic (src/train_wgan_v2.py:129-160, called per critic batch at :523-524 with bounds
+ * 0, 10): per alignment n ~ U{lower..upper} distinct random columns, the first n / 2 set to 0.0 and the rest to 1.0 over
+ * all rows, each one's position redrawn uniformly between its current neighbours (0 / 1 at the ends), in the order
+ * drawn.  n_given [B], cols_given [B][upper], u_given [B][upper]: all NULL, or the draws to use (tests).  The B
+ * alignments are numbers first .. first + B - 1 of a global batch of `total`.  upper <= 15, S <= 128. */
+int pgan_label_smooth(float* sites, long long n, float noise, float centre, int normalized, unsigned int* rng,
+                      const float* ey_given, long long skip, long long total, hipStream_t st);
+int pgan_mono_switch(float* sites, float* pos, int B, int rows, int S, int lower, int upper, unsigned int* rng,
+                     const int* n_given, const int* cols_given, const float* u_given, int first, int total,
+                     hipStream_t st);
 
 /* ---- discriminator 1-D tower, src/layers.py:470-480.  params: 12 device pointers
  * (conv w, conv b, gn w, gn b) x 3.  a1 [N][16][61], a2 [N][32][58], a3 [N][64][55] keep the conv
@@ -301,6 +330,38 @@ int pgan_step_graph_begin(hipStream_t st);
 int pgan_step_graph_end(hipStream_t st, void** graph_exec);
 int pgan_step_graph_launch(void* graph_exec, hipStream_t st);
 int pgan_step_graph_destroy(void* graph_exec);
+
+/* "gfx950 packed-fp32-ops=off" for a library whose device code was built without packed-fp32 vector instructions (the
+ * only supported build: see csrc/runtime.hip), "...=on" otherwise.  No counterpart in the reference. */
+const char* pgan_build_info(void);
+
+/* ---- cross-stream ordering of a step's side streams (the reference runs on one stream; no counterpart).  Events
+ * are created once, before anything is recorded, and reused: pgan_stream_edge(ev, from, to) makes work enqueued on `to`
+ * afterwards wait for what `from` holds now (record + wait; under an open capture it becomes a graph edge);
+ * pgan_event_record / pgan_stream_wait_event are its two halves, for a mark that is waited for later.  No call here
+ * creates or destroys anything except _create / _destroy; pgan_events_created() counts the former, so a caller can
+ * assert that none happened while a capture was open. */
+int pgan_event_create(void** ev);
+int pgan_event_destroy(void* ev);
+long long pgan_events_created(void);
+int pgan_event_record(void* ev, hipStream_t st);
+int pgan_stream_wait_event(hipStream_t st, void* ev);
+int pgan_stream_edge(void* ev, hipStream_t from, hipStream_t to);
+
+/* ---- launch tape: one iteration's enqueue calls (the loop body of src/train_wgan_v2.py:516-634, which the reference
+ * drives op by op from Python) noted once and replayed by one call.  pgan_tape_append notes a call of the named entry
+ * point of this header (enqueue entry points only) with one 64-bit word per argument in declaration order: integers
+ * sign-extended, pointers as addresses, floats as their 32 bits in the low half; host arrays an argument points to
+ * must stay alive as long as the tape.  pgan_tape_replay makes the calls in order; it stops at the first one that does
+ * not return 0, stores its index in *failed_at (may be NULL) and returns that call's code.  pgan_tape_arg_count: words
+ * the named entry point takes, -1 if it cannot be noted. */
+void* pgan_tape_create(void);
+int pgan_tape_destroy(void* tape);
+int pgan_tape_arg_count(const char* entry_point);
+int pgan_tape_append(void* tape, const char* entry_point, const unsigned long long* words, int nwords);
+int pgan_tape_length(void* tape);
+int pgan_tape_replay(void* tape, int* failed_at);
+const char* pgan_tape_entry_name(void* tape, int index);
 
 #ifdef __cplusplus
 }

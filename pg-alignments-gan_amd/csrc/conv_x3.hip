@@ -1220,6 +1220,15 @@ int FN_PREP(const float* W, void* planes, int Cs, int Cl, hipStream_t st) {
     return pgan_launch_status();
 }
 
+#ifdef PGAN_SPLIT_F16
+// Forget the largest |w| a prepared-weight buffer has seen (its header word), stream-ordered: the next preparation
+// starts the record again.  For weights that are unrelated to the ones prepared before (a load, another tensor).
+int pgan_conv_h2_forget(void* planes, hipStream_t st) {
+    if (!planes) return PGAN_EINVAL;
+    return hipMemsetAsync(planes, 0, WHDR_BYTES, st) == hipSuccess ? PGAN_OK : PGAN_ELAUNCH;
+}
+#endif
+
 // The same for n <= 6 weight tensors in two launches (one in the bf16 split) instead of two per tensor.
 int FN_PREP_MULTI(const float* const* W, void* const* planes, const int* Cs, const int* Cl, int n, hipStream_t st) {
     if (n <= 0 || n > PREP_MAX || !W || !planes || !Cs || !Cl) return PGAN_EINVAL;

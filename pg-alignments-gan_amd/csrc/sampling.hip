@@ -1,5 +1,7 @@
 // Device-side random sampling steps around the training step, all driven by the same Philox4x32-10 state words as
 // pgan_philox (state[0..1] seed, state[2..3] 64-bit offset in units of one Philox call = 4 outputs):
+//   * per-batch augmentations of the real alignments: label smoothing (src/train_wgan_v2.py:265-268) and monomorphic
+//     site switching (:129-160,523-524), drawn afresh for every batch inside the recorded step;
 //   * replay buffer of generated alignments (FakeBuffer, src/train_wgan_v2.py:98-117): bounded FIFO + a batch drawn
 //     from it without replacement, as three tiny launches so that the critic step that uses it stays inside a
 //     recorded launch tape / hipGraph (no host random numbers, no host integers);
@@ -163,11 +165,130 @@ __global__ __launch_bounds__(256) void sample_genotypes_kernel(const float* __re
     }
     for (int i = 0; i < ROWS; ++i) ocol[(int64_t)i * S] = (float)((m[i >> 6] >> (i & 63)) & 1ull);
 }
-__global__ void genotype_rng_advance_kernel(uint32_t* rng, uint64_t calls) { philox_bump(rng, calls); }
+// ---------------- per-batch augmentations of the real alignments ----------------
+// Label smoothing: x' = x (1 - ey) + centre ey with ey ~ U(0, noise), one draw per element; value v of the batch's draw
+// comes from Philox call (skip + v) / 4.  normalized: x holds (raw - 0.5) / 0.5 (the pool is normalised once when it is
+// loaded; the reference smooths the raw values inside get_batch and normalises afterwards, :265-268 then :519-521).
+// ey_given: the draws themselves (tests).
+__global__ void label_smooth_kernel(float* __restrict__ x, int64_t n4, int64_t skip4, float noise, float centre,
+                                    int normalized, const uint32_t* __restrict__ rng, const float* __restrict__ ey_given) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 ey;
+    if (ey_given) {
+        ey = reinterpret_cast<const f32x4*>(ey_given)[i];
+    } else {
+        uint32_t c[4];
+        philox4(philox_offset(rng) + (uint64_t)(skip4 + i), rng[0], rng[1], c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ey[e] = noise * ((c[e] >> 8) * (1.0f / 16777216.0f));
+    }
+    f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float raw = normalized ? fmaf(v[e], 0.5f, 0.5f) : v[e];
+        const float sm = fmaf(raw, 1.f - ey[e], centre * ey[e]);
+        v[e] = normalized ? fmaf(sm, 2.f, -1.f) : sm;
+    }
+    reinterpret_cast<f32x4*>(x)[i] = v;
+}
+
+// switch_monomorphic (src/train_wgan_v2.py:129-160), one block per alignment.  Thread 0 makes the alignment's draws --
+// n ~ U{lower..upper} columns (random.randint), an ordered sample of n distinct columns (np.random.choice without
+// replacement: partial Fisher-Yates), one uniform per chosen column -- and redraws the chosen columns' positions one
+// after the other between the CURRENT neighbours (0 below the first column, 1 above the last), in double precision as
+// numpy does, so a neighbour redrawn earlier in the loop already counts; then all threads write the columns: the first
+// n / 2 all 0.0, the rest all 1.0 (these literals also after --normalize, as in the reference, where the switch runs
+// on the normalised batch).  MONO_CALLS Philox calls are reserved per alignment, keyed by its index in the global batch.
+constexpr int MONO_CALLS = 8;       // 1 + 2 * MONO_MAX words
+constexpr int MONO_MAX = 15;        // most columns switched per alignment
+__global__ __launch_bounds__(64) void mono_switch_kernel(float* __restrict__ sites, float* __restrict__ pos, int rows, int S,
+                                                         int lower, int upper, const uint32_t* __restrict__ rng,
+                                                         const int* __restrict__ n_given, const int* __restrict__ cols_given,
+                                                         const float* __restrict__ u_given, int first) {
+    __shared__ int perm[128];
+    __shared__ int cols[MONO_MAX];
+    __shared__ int count;
+    const int a = blockIdx.x;
+    float* P = pos + (int64_t)a * S;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) perm[i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t w[4 * MONO_CALLS];
+        int n;
+        if (n_given) {
+            n = min(max(n_given[a], 0), min(upper, S));
+        } else {
+            const uint64_t base = philox_offset(rng) + (uint64_t)(first + a) * MONO_CALLS;
+#pragma unroll
+            for (int k = 0; k < MONO_CALLS; ++k) {
+                uint32_t c[4];
+                philox4(base + k, rng[0], rng[1], c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[4 * k + e] = c[e];
+            }
+            n = lower + (int)__umulhi(w[0], (uint32_t)(upper - lower + 1));
+        }
+        for (int k = 0; k < n; ++k) {
+            int col;
+            if (cols_given) {
+                col = min(max(cols_given[a * upper + k], 0), S - 1);
+            } else {
+                const int j = k + (int)__umulhi(w[1 + k], (uint32_t)(S - k));
+                col = perm[j];
+                perm[j] = perm[k];
+                perm[k] = col;
+            }
+            cols[k] = col;
+        }
+        for (int k = 0; k < n; ++k) {
+            const int i = cols[k];
+            const float u = u_given ? u_given[a * upper + k] : (w[1 + MONO_MAX + k] >> 8) * (1.0f / 16777216.0f);
+            const double lo = i == 0 ? 0.0 : (double)P[i - 1], hi = i == S - 1 ? 1.0 : (double)P[i + 1];
+            P[i] = (float)(lo + (hi - lo) * (double)u);
+        }
+        count = n;
+    }
+    __syncthreads();
+    const int n = count;
+    float* X = sites + (int64_t)a * rows * S;
+    for (int k = 0; k < n; ++k) {
+        const float v = k < n / 2 ? 0.f : 1.f;
+        for (int r = threadIdx.x; r < rows; r += blockDim.x) X[(int64_t)r * S + cols[k]] = v;
+    }
+}
+__global__ void rng_advance_kernel(uint32_t* rng, uint64_t calls) { philox_bump(rng, calls); }
 
 }  // namespace
 
 extern "C" {
+
+// sites[n] <- label-smoothed sites (see label_smooth_kernel): n values of a batch whose first value is number `skip` of
+// a draw of `total` values (the global batch of a data-parallel run; one GPU: skip 0, total n).  n, skip % 4 == 0.
+int pgan_label_smooth(float* sites, long long n, float noise, float centre, int normalized, unsigned int* rng,
+                      const float* ey_given, long long skip, long long total, hipStream_t st) {
+    if (n <= 0 || n % 4 || skip < 0 || skip % 4 || skip + n > total || !sites || (!rng && !ey_given)) return PGAN_EINVAL;
+    label_smooth_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(sites, n / 4, skip / 4, noise, centre, normalized,
+                                                                       rng, ey_given);
+    if (!ey_given) rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)((total + 3) / 4));
+    return pgan_launch_status();
+}
+
+// switch_monomorphic on a batch of B alignments (sites [B][1][rows][S], pos [B][1][S]) that are alignments
+// first .. first + B - 1 of a global batch of `total`; n_given / cols_given / u_given ([B], [B][upper], [B][upper]) replace
+// the draws (tests); upper <= 15, S <= 128.
+int pgan_mono_switch(float* sites, float* pos, int B, int rows, int S, int lower, int upper, unsigned int* rng,
+                     const int* n_given, const int* cols_given, const float* u_given, int first, int total,
+                     hipStream_t st) {
+    if (B <= 0 || rows <= 0 || S <= 1 || S > 128 || lower < 0 || upper < lower || upper > MONO_MAX || upper > S || !sites ||
+        !pos || first < 0 || first + B > total)
+        return PGAN_EINVAL;
+    const bool given = n_given && cols_given && u_given;
+    if (!given && (!rng || n_given || cols_given || u_given)) return PGAN_EINVAL;      // all three or none
+    mono_switch_kernel<<<B, 64, 0, st>>>(sites, pos, rows, S, lower, upper, rng, n_given, cols_given, u_given, first);
+    if (!given) rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)total * MONO_CALLS);
+    return pgan_launch_status();
+}
 
 // One replay-buffer step: append the B alignments new_s / new_p (Ms / Mp floats each) to the ring buf_s / buf_p
 // (`size` <= 16320 slots), then write B alignments drawn from the buffer without replacement to out_s / out_p.
@@ -195,7 +316,7 @@ int pgan_sample_genotypes(const float* p, float* out, long long n, int rows, int
     const unsigned grid = (unsigned)((ncol + 255) / 256);
     if (rows == 64) sample_genotypes_kernel<64><<<grid, 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
     else sample_genotypes_kernel<128><<<grid, 256, 0, st>>>(p, out, ncol, S, rng, require_variation);
-    genotype_rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)ncol * GT_CALLS);
+    rng_advance_kernel<<<1, 1, 0, st>>>(rng, (uint64_t)ncol * GT_CALLS);
     return pgan_launch_status();
 }
 

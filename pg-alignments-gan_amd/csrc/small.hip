@@ -137,7 +137,7 @@ __global__ void adam_tick_kernel(int* step_dev) { step_dev[0] += 1; }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                            const int* __restrict__ step_dev, int step_host) {
+                            float grad_scale, const int* __restrict__ step_dev, int step_host) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n / 4) return;
     const int step = step_dev ? step_dev[0] : step_host;
@@ -145,7 +145,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const double bc2 = 1.0 - pow((double)b2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    // grad_scale: 1 / ranks of a data-parallel run whose gradient buffers hold sums over the ranks (times 1 is exact)
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * grad_scale;
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pp = reinterpret_cast<f32x4*>(p)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -172,9 +173,11 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
     k[1] += 0xBB67AE85u;
 }
 
-__global__ void philox_kernel(float* __restrict__ out, int64_t n, const uint32_t* __restrict__ state, int normal) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 outputs
-    if (i * 4 >= n) return;
+// Values [skip, skip + n) of the draw that starts at the state's offset (value v comes from Philox call v / 4).
+__global__ void philox_kernel(float* __restrict__ out, int64_t n, int64_t skip, const uint32_t* __restrict__ state,
+                              int normal) {
+    const int64_t i = (skip >> 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 outputs
+    if (i * 4 >= skip + n) return;
     const uint64_t off = ((uint64_t)state[3] << 32 | state[2]) + (uint64_t)i;
     uint32_t c[4] = {(uint32_t)off, (uint32_t)(off >> 32), 0u, 0u};
     uint32_t k[2] = {state[0], state[1]};
@@ -197,11 +200,13 @@ __global__ void philox_kernel(float* __restrict__ out, int64_t n, const uint32_t
         for (int e = 0; e < 4; ++e) o[e] = (c[e] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (i * 4 + e < n) out[i * 4 + e] = o[e];
+    for (int e = 0; e < 4; ++e) {
+        const int64_t v = i * 4 + e - skip;
+        if (v >= 0 && v < n) out[v] = o[e];
+    }
 }
 
-__global__ void philox_advance_kernel(uint32_t* state, uint32_t groups) {
+__global__ void philox_advance_kernel(uint32_t* state, uint64_t groups) {
     const uint64_t off = ((uint64_t)state[3] << 32 | state[2]) + groups;
     state[2] = (uint32_t)off;
     state[3] = (uint32_t)(off >> 32);
@@ -210,9 +215,9 @@ __global__ void philox_advance_kernel(uint32_t* state, uint32_t groups) {
 // out_s[b] = pool_s[(cursor + b) % npool], same for positions; cursor lives in device memory.
 __global__ void take_batch_kernel(const float* __restrict__ pool_s, const float* __restrict__ pool_p,
                                   float* __restrict__ out_s, float* __restrict__ out_p, const int* __restrict__ cursor,
-                                  int npool, int B, int Ms, int Mp) {
+                                  int npool, int B, int Ms, int Mp, int offset) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = cursor[0];
+    const int c0 = (cursor[0] + offset) % npool;
     if (i < (int64_t)B * Ms / 4) {
         const int b = (int)(i / (Ms / 4)), e = (int)(i % (Ms / 4));
         const int src = (c0 + b) % npool;
@@ -297,29 +302,42 @@ int pgan_affine(const float* x, float* out, long long n, float scale, float shif
 // n must be a multiple of 4 (flat parameter stores are padded).  step_dev (device int, may be null):
 // incremented, then used as the step count; otherwise `step` is used.
 int pgan_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-              int* step_dev, int step, hipStream_t st) {
+              float grad_scale, int* step_dev, int step, hipStream_t st) {
     if (n <= 0 || n % 4) return PGAN_EINVAL;
     if (step_dev) adam_tick_kernel<<<1, 1, 0, st>>>(step_dev);
-    adam_kernel<<<grid_for(n / 4, 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, step_dev, step);
+    adam_kernel<<<grid_for(n / 4, 256), 256, 0, st>>>(p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev, step);
     return pgan_launch_status();
 }
 
 // Next B alignments of a device-resident pool (wrapping), then cursor += B.
-int pgan_take_batch(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool, int B,
-                    int Ms, int Mp, hipStream_t st) {
-    if (B <= 0 || npool <= 0 || Ms % 4 || Mp % 4 || Mp > Ms) return PGAN_EINVAL;
-    take_batch_kernel<<<grid_for((int64_t)B * Ms / 4, 256), 256, 0, st>>>(pool_s, pool_p, out_s, out_p, cursor, npool, B, Ms, Mp);
-    cursor_advance_kernel<<<1, 1, 0, st>>>(cursor, npool, B);
+int pgan_take_batch_slice(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool,
+                          int B, int Ms, int Mp, int offset, int advance, hipStream_t st) {
+    if (B <= 0 || npool <= 0 || Ms % 4 || Mp % 4 || Mp > Ms || offset < 0 || advance < 0 || !cursor) return PGAN_EINVAL;
+    take_batch_kernel<<<grid_for((int64_t)B * Ms / 4, 256), 256, 0, st>>>(pool_s, pool_p, out_s, out_p, cursor, npool, B, Ms,
+                                                                          Mp, offset % npool);
+    cursor_advance_kernel<<<1, 1, 0, st>>>(cursor, npool, advance % npool);
     return pgan_launch_status();
 }
 
+int pgan_take_batch(const float* pool_s, const float* pool_p, float* out_s, float* out_p, int* cursor, int npool, int B,
+                    int Ms, int Mp, hipStream_t st) {
+    return pgan_take_batch_slice(pool_s, pool_p, out_s, out_p, cursor, npool, B, Ms, Mp, 0, B, st);
+}
+
 // state: 4 x uint32 in device memory (seed lo, seed hi, offset lo, offset hi).  normal: 1 -> N(0,1), 0 -> U[0,1).
-int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStream_t st) {
-    if (n <= 0) return PGAN_EINVAL;
-    const long long groups = (n + 3) / 4;
-    philox_kernel<<<grid_for(groups, 256), 256, 0, st>>>(out, n, state, normal);
-    philox_advance_kernel<<<1, 1, 0, st>>>(state, (uint32_t)groups);
+// Values [skip, skip + n) of a draw of `total` values; the state advances by the whole draw.  Ranks of a data-parallel run
+// that share one generator state each take their rows of the global draw this way.
+int pgan_philox_slice(float* out, long long n, long long skip, long long total, unsigned int* state, int normal,
+                      hipStream_t st) {
+    if (n <= 0 || skip < 0 || skip + n > total || !out || !state) return PGAN_EINVAL;
+    const long long groups = (skip + n + 3) / 4 - skip / 4;
+    philox_kernel<<<grid_for(groups, 256), 256, 0, st>>>(out, n, skip, state, normal);
+    philox_advance_kernel<<<1, 1, 0, st>>>(state, (uint64_t)((total + 3) / 4));
     return pgan_launch_status();
+}
+
+int pgan_philox(float* out, long long n, unsigned int* state, int normal, hipStream_t st) {
+    return pgan_philox_slice(out, n, 0, n, state, normal, st);
 }
 
 // One training step (any sequence of the entry points above, on `st` and on streams forked from it with events) as

@@ -29,8 +29,6 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-import pgan_tape
-
 LATENT = 128
 DATA = 64
 D2_CH = (1, 64, 128, 256, 512)      # discriminator 2-D tower channels (layers.py:441-463)
@@ -158,36 +156,42 @@ class SideStream:
     """Second HIP stream for the small position-vector towers: they are latency-bound chains of tiny
     kernels that depend only on parameters and their own inputs, so they run beside the 2-D towers'
     large convolution kernels (also under graph capture, where fork/join become graph edges).
-    On the CPU backend every method is a no-op."""
+    Fork, join and mark are edges over three events of the library that exist before anything is enqueued
+    (pgan_hip.Event): no edge creates or destroys an object, also not while a capture is open, and a launch tape
+    notes them like any other library call.  On the CPU backend every method is a no-op."""
 
     def __init__(self, device):
         # Default priority on purpose: with streams of different priority classes the step deadlocked on the GPU (a
         # higher-class hardware queue blocked on an event of a lower-class queue kept that queue from being served).
         self.enabled = torch.device(device).type == "cuda"
         if self.enabled:
+            import pgan_hip
             # PGAN_SERIAL_STREAMS=1 (debugging aid): every side stream is the caller's stream, so nothing overlaps
             serial = os.environ.get("PGAN_SERIAL_STREAMS", "0") == "1"
             self.stream = torch.cuda.current_stream(device) if serial else torch.cuda.Stream(device=device)
-            self.mark = torch.cuda.Event()
+            self.raw = self.stream.cuda_stream
+            self._cur = pgan_hip._stream
+            self.ev_fork, self.ev_join, self.mark = pgan_hip.Event(), pgan_hip.Event(), pgan_hip.Event()
 
-    # The waits go through pgan_tape.call: a launch tape being recorded notes them with the stream objects of now.
     def fork(self):
+        """The side stream waits for what the current stream holds now."""
         if self.enabled:
-            pgan_tape.call(self.stream.wait_stream, torch.cuda.current_stream())
+            self.ev_fork.edge(self._cur(), self.raw)
 
     def join(self):
+        """The current stream waits for what the side stream holds now."""
         if self.enabled:
-            pgan_tape.call(torch.cuda.current_stream().wait_stream, self.stream)
+            self.ev_join.edge(self.raw, self._cur())
 
     def set_mark(self):
-        """Called on the side stream: remember this point."""
+        """Remember this point of the side stream."""
         if self.enabled:
-            pgan_tape.call(self.mark.record, self.stream)
+            self.mark.record(self.raw)
 
     def wait_mark(self):
-        """Called on the main stream: wait for the side stream's mark."""
+        """The current stream waits for the side stream's mark."""
         if self.enabled:
-            pgan_tape.call(torch.cuda.current_stream().wait_event, self.mark)
+            self.mark.wait(self._cur())
 
     def __enter__(self):
         if self.enabled:
@@ -260,6 +264,9 @@ class Engine:
         # the ranks in place on the current stream, bn_world = number of ranks; None: statistics of this rank's batch
         self.bn_sync = None
         self.bn_world = 1
+        # factor Adam applies to the gradients as it reads them: 1 / ranks when the flat gradient buffers hold sums over
+        # the ranks of a data-parallel run
+        self.grad_scale = 1.0
         self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
         # weight gradients of the Wasserstein samples right after their backward, the penalised samples' share added
         # later (two half-size passes per stage instead of one): the first half leaves the weight-gradient stream early,
@@ -870,11 +877,13 @@ class Engine:
 
     def _adam(self, st: FlatStore, lr: float) -> None:
         st.step += 1
+        scale = {} if self.grad_scale == 1.0 else {"grad_scale": self.grad_scale}
         if getattr(st, "step_dev", None) is not None:
             self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, 0, lr, self.betas[0], self.betas[1], self.eps,
-                          st.step_dev)
+                          st.step_dev, **scale)
         else:
-            self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, st.step, lr, self.betas[0], self.betas[1], self.eps)
+            self.ops.adam(st.flat, st.gflat, st.mflat, st.vflat, st.step, lr, self.betas[0], self.betas[1], self.eps,
+                          **scale)
         stale = getattr(self.ops, "invalidate_weight_planes", None)
         if stale is not None:     # prepared copies of this store's convolution weights are rebuilt at their next use
             stale(st.flat)

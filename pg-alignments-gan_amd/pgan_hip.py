@@ -26,7 +26,18 @@ def _load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
-    return ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    # Device code built with packed-fp32 vector instructions returned wrong values beside other streams' kernels on this
+    # part: a library that does not state the build without them is refused (PGAN_PACKED_FP32=1: comparison builds).
+    try:
+        lib.pgan_build_info.restype = ctypes.c_char_p
+        info = (lib.pgan_build_info() or b"").decode()
+    except AttributeError:
+        info = "unknown (no pgan_build_info)"
+    if "packed-fp32-ops=off" not in info and os.environ.get("PGAN_PACKED_FP32", "0") != "1":
+        raise ImportError(f"{LIB_PATH} was built as '{info}': rebuild it through __graft_entry__.build(), which compiles "
+                          f"the device code without packed-fp32 instructions")
+    return lib
 
 
 _lib = _load()
@@ -42,6 +53,7 @@ _SIGS = {
     "pgan_conv_up_x3": [P, P, P, I, I, I, I, P, I, I, P],
     "pgan_conv_wgrad_x3": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_conv_h2_prep": [P, P, I, I, P],
+    "pgan_conv_h2_forget": [P, P],
     "pgan_conv_h2_prep_multi": [P, P, P, P, I, P],
     "pgan_conv_x3_prep_multi": [P, P, P, P, I, P],
     "pgan_conv_down_h2": [P, P, P, I, I, I, I, P, I, I, P],
@@ -70,9 +82,16 @@ _SIGS = {
     "pgan_sum_scale": [P, P, I, F, P],
     "pgan_act_bwd": [P, P, P, L, I, P],
     "pgan_affine": [P, P, L, F, F, P],
-    "pgan_adam": [P, P, P, P, L, F, F, F, F, P, I, P],
+    "pgan_adam": [P, P, P, P, L, F, F, F, F, F, P, I, P],
     "pgan_philox": [P, L, P, I, P],
+    "pgan_philox_slice": [P, L, L, L, P, I, P],
     "pgan_take_batch": [P, P, P, P, P, I, I, I, I, P],
+    "pgan_take_batch_slice": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "pgan_label_smooth": [P, L, F, F, I, P, P, L, L, P],
+    "pgan_mono_switch": [P, P, I, I, I, I, I, P, P, P, P, I, I, P],
+    "pgan_event_record": [P, P],
+    "pgan_stream_wait_event": [P, P],
+    "pgan_stream_edge": [P, P, P],
     "pgan_d1d_fwd": [P, P, P, P, P, P, I, P],
     "pgan_d1d_bwd": [P, P, P, P, P, P, P, P, I, P, P, I, P],
     "pgan_d1d_fwd_len": [P, P, P, P, P, P, I, I, P],
@@ -92,12 +111,20 @@ _SIGS = {
     "pgan_step_graph_end": [P, ctypes.POINTER(ctypes.c_void_p)],
     "pgan_step_graph_launch": [P, P],
     "pgan_step_graph_destroy": [P],
+    "pgan_event_create": [ctypes.POINTER(ctypes.c_void_p)],
+    "pgan_event_destroy": [P],
+    "pgan_tape_destroy": [P],
+    "pgan_tape_arg_count": [ctypes.c_char_p],
+    "pgan_tape_append": [P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong), I],
+    "pgan_tape_length": [P],
+    "pgan_tape_replay": [P, ctypes.POINTER(c_int)],
 }
 EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_option", "pgan_x3_set_option",
                                 "pgan_conv_x3_prep_bytes", "pgan_conv_wgrad_x3_workspace_floats", "pgan_h2_set_option",
                                 "pgan_conv_h2_prep_bytes", "pgan_conv_wgrad_h2_workspace_floats",
                                 "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials",
-                                "pgan_bn_fwd_partials", "pgan_gn_fwd_static_max_samples"])
+                                "pgan_bn_fwd_partials", "pgan_gn_fwd_static_max_samples", "pgan_build_info",
+                                "pgan_events_created", "pgan_tape_create", "pgan_tape_entry_name"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
@@ -114,6 +141,12 @@ _lib.pgan_gn_fwd_static_max_samples.argtypes = []
 _lib.pgan_gn_fwd_static_max_samples.restype = c_int
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
+_lib.pgan_events_created.argtypes = []
+_lib.pgan_events_created.restype = c_longlong
+_lib.pgan_tape_create.argtypes = []
+_lib.pgan_tape_create.restype = c_void_p
+_lib.pgan_tape_entry_name.argtypes = [P, I]
+_lib.pgan_tape_entry_name.restype = ctypes.c_char_p
 for _fn in (_lib.pgan_conv_wgrad_x3_workspace_floats, _lib.pgan_conv_wgrad_h2_workspace_floats):
     _fn.argtypes = [I, I, I, I]
     _fn.restype = c_longlong
@@ -148,7 +181,8 @@ class _Lib:
     """The loaded library with its enqueue entry points wrapped for tape recording (queries and host-side functions
     pass through untouched)."""
     _HOST = ("pgan_parse_alignments", "pgan_parse_ms", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
-             "pgan_step_graph_destroy")
+             "pgan_step_graph_destroy", "pgan_event_create", "pgan_event_destroy", "pgan_tape_destroy", "pgan_tape_arg_count",
+             "pgan_tape_append", "pgan_tape_length", "pgan_tape_replay")
 
     def __init__(self, lib):
         self._real = lib
@@ -161,6 +195,94 @@ class _Lib:
 
 
 _lib = _Lib(_lib)
+
+
+class Event:
+    """An event of the library (created once, reused): the marks and fork / join edges between the engine's streams.  Edges
+    made through these calls create and destroy nothing, so they are safe while a graph capture is open, and a launch
+    tape notes them like any other enqueue call."""
+    __slots__ = ("handle",)
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _check(_lib.pgan_event_create(ctypes.byref(h)), "pgan_event_create")
+        self.handle = h.value
+
+    def record(self, stream: int) -> None:
+        _check(_lib.pgan_event_record(self.handle, stream), "pgan_event_record")
+
+    def wait(self, stream: int) -> None:
+        """Work enqueued on `stream` (raw handle) from now on waits for the event's last record."""
+        _check(_lib.pgan_stream_wait_event(stream, self.handle), "pgan_stream_wait_event")
+
+    def edge(self, src: int, dst: int) -> None:
+        """Work enqueued on dst from now on waits for everything src holds now."""
+        _check(_lib.pgan_stream_edge(self.handle, src, dst), "pgan_stream_edge")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            _lib.pgan_event_destroy(h)
+
+
+def events_created() -> int:
+    """Events the library has created so far (a capture asserts that the count does not move while it is open)."""
+    return int(_lib.pgan_events_created())
+
+
+def _arg_word(kind, v) -> int:
+    """One tape word for argument v of ctypes kind `kind` (see pgan_tape_append)."""
+    if kind is c_float:
+        import struct
+        return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+    if kind is c_void_p:
+        if v is None:
+            return 0
+        if isinstance(v, int):
+            return v & 0xFFFFFFFFFFFFFFFF
+        if isinstance(v, ctypes.c_void_p):
+            return (v.value or 0) & 0xFFFFFFFFFFFFFFFF
+        return ctypes.addressof(v)              # a ctypes array / structure kept alive by the tape's entry list
+    return int(v) & 0xFFFFFFFFFFFFFFFF          # c_int / c_longlong: two's complement, sign-extended
+
+
+class NativeTape:
+    """A stretch of library enqueue calls replayed by one pgan_tape_replay call."""
+
+    def __init__(self, entries):
+        self.handle = _lib.pgan_tape_create()
+        if not self.handle:
+            raise PganError("pgan_tape_create failed")
+        self.keep = entries                     # host arrays the noted pointers refer to
+        for fn, args, _ in entries:
+            name = fn.__name__
+            kinds = _SIGS[name]
+            words = (ctypes.c_ulonglong * len(kinds))(*[_arg_word(k, a) for k, a in zip(kinds, args)])
+            _check(_lib.pgan_tape_append(self.handle, name.encode(), words, len(kinds)), f"pgan_tape_append({name})")
+        self._failed = c_int(-1)
+
+    @staticmethod
+    def accepts(fn) -> bool:
+        name = getattr(fn, "__name__", None)
+        return name in _SIGS and _lib.pgan_tape_arg_count(name.encode()) == len(_SIGS[name])
+
+    def __len__(self):
+        return int(_lib.pgan_tape_length(self.handle))
+
+    def replay(self) -> None:
+        rc = _lib.pgan_tape_replay(self.handle, ctypes.byref(self._failed))
+        if rc:
+            name = _lib.pgan_tape_entry_name(self.handle, self._failed.value)
+            raise PganError(f"{(name or b'?').decode()} (call {self._failed.value} of the tape) failed with code {rc} "
+                            f"during tape replay")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            _lib.pgan_tape_destroy(h)
+
+
+pgan_tape.native_tape = NativeTape
 
 
 def set_option(name: str, value: int) -> None:
@@ -339,6 +461,22 @@ class HipOps:
             self._planes[key] = ent
         return ent
 
+    def _forget(self, ent) -> None:
+        """Start the planes buffer's record of the largest |w| again (a library call on the current stream, so a launch
+        tape or graph that is being recorded holds it like the preparation that follows)."""
+        _check(_lib.pgan_conv_h2_forget(ent[0].data_ptr(), _stream()), "pgan_conv_h2_forget")
+
+    def settle_weight_planes(self) -> None:
+        """Apply pending resets of the running weight maxima now, on the current stream.  Called before an iteration is
+        recorded (tape or graph) so that the recorded launches hold preparations only: a replay then keeps the maxima
+        growing exactly as eager iterations do, whatever happened to the weights before the recording."""
+        if self.precision == "h2":
+            for ent in self._planes.values():
+                if ent[2]:
+                    self._forget(ent)
+                    ent[2] = False
+                    ent[1] = False
+
     def _planes_stale(self, w) -> bool:
         return not (self._planes_entry(w)[1] and (self.static_weights or self._hold))
 
@@ -349,7 +487,7 @@ class HipOps:
         keep = self.static_weights or self._hold
         if not (ent[1] and keep):
             if h2 and (ent[2] or not keep):      # header word 0: largest |w| prepared so far (see pgan_conv_h2_prep)
-                ent[0][:4].zero_()
+                self._forget(ent)
             ent[2] = False
             prep = _lib.pgan_conv_h2_prep if h2 else _lib.pgan_conv_x3_prep
             _check(prep(_ptr(w), ent[0].data_ptr(), Cs, Cl, _stream()), "pgan_conv_prep")
@@ -476,7 +614,7 @@ class HipOps:
                 ents = [self._planes_entry(w) for w in todo]
                 for ent in ents:
                     if h2 and (ent[2] or not self.static_weights):
-                        ent[0][:4].zero_()
+                        self._forget(ent)
                     ent[2] = False
                 n = len(todo)
                 wa = (c_void_p * n)(*[_ptr(w) for w in todo])
@@ -631,18 +769,52 @@ class HipOps:
     def affine(self, x, scale, shift, out):
         _check(_lib.pgan_affine(_ptr(x), _ptr(out), x.numel(), float(scale), float(shift), _stream()), "pgan_affine")
 
-    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None):
+    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None, grad_scale=1.0):
+        """grad_scale: factor applied to g as it is read (1 / ranks when g holds a sum over data-parallel ranks)."""
         sd = None if step_dev is None else step_dev.data_ptr()
-        _check(_lib.pgan_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, b1, b2, eps, sd, int(step), _stream()),
-               "pgan_adam")
+        _check(_lib.pgan_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, b1, b2, eps, float(grad_scale), sd,
+                              int(step), _stream()), "pgan_adam")
 
-    def philox(self, out, state, normal: bool):
-        _check(_lib.pgan_philox(_ptr(out), out.numel(), state.data_ptr(), int(normal), _stream()), "pgan_philox")
+    def philox(self, out, state, normal: bool, skip: int = 0, total: Optional[int] = None):
+        """out = values [skip, skip + out.numel()) of a draw of `total` values (default: the whole draw); the state
+        advances by the whole draw."""
+        n = out.numel()
+        _check(_lib.pgan_philox_slice(_ptr(out), n, int(skip), n if total is None else int(total), state.data_ptr(),
+                                      int(normal), _stream()), "pgan_philox_slice")
 
-    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor):
+    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor, offset: int = 0, advance: Optional[int] = None):
+        """offset / advance: the batch starts `offset` alignments past the cursor, which then moves on by `advance`
+        (default: the batch size) -- a rank's rows of a global batch."""
         B = out_s.shape[0]
-        _check(_lib.pgan_take_batch(_ptr(pool_s), _ptr(pool_p), _ptr(out_s), _ptr(out_p), cursor.data_ptr(),
-                                    pool_s.shape[0], B, out_s[0].numel(), out_p[0].numel(), _stream()), "pgan_take_batch")
+        _check(_lib.pgan_take_batch_slice(_ptr(pool_s), _ptr(pool_p), _ptr(out_s), _ptr(out_p), cursor.data_ptr(),
+                                          pool_s.shape[0], B, out_s[0].numel(), out_p[0].numel(), int(offset),
+                                          B if advance is None else int(advance), _stream()), "pgan_take_batch_slice")
+
+    # ---------------- per-batch augmentations of the real alignments ----------------
+    def label_smooth(self, sites, noise, centre, normalized, rng, ey=None, skip: int = 0, total: Optional[int] = None):
+        """sites <- sites (1 - ey) + centre ey in place, ey ~ U(0, noise) per element from the device generator `rng`
+        (or the given draws `ey`, same shape); normalized: sites hold (raw - 0.5) / 0.5."""
+        n = sites.numel()
+        if ey is not None and (ey.numel() != n or not ey.is_cuda):
+            raise PganError("label_smooth: the given draws must match the sites")
+        _check(_lib.pgan_label_smooth(_ptr(sites), n, float(noise), float(centre), int(bool(normalized)),
+                                      None if rng is None else rng.data_ptr(), _ptr(ey), int(skip),
+                                      n if total is None else int(total), _stream()), "pgan_label_smooth")
+
+    def mono_switch(self, sites, pos, lower, upper, rng, given=None, first: int = 0, total: Optional[int] = None):
+        """switch_monomorphic in place on sites [B,1,rows,S] / pos [B,1,S]; given = (n [B] int32, cols [B, upper] int32,
+        u [B, upper] float32) replaces the device draws."""
+        B, rows, S = sites.shape[0], sites.shape[2], sites.shape[3]
+        assert tuple(pos.shape) == (B, 1, S) and sites.shape[1] == 1
+        gn = gc = gu = None
+        if given is not None:
+            n_g, c_g, u_g = given
+            assert n_g.dtype == torch.int32 and c_g.dtype == torch.int32 and n_g.numel() >= B
+            assert c_g.numel() >= B * upper and u_g.numel() >= B * upper and n_g.is_cuda and c_g.is_cuda
+            gn, gc, gu = n_g.data_ptr(), c_g.data_ptr(), _ptr(u_g)
+        _check(_lib.pgan_mono_switch(_ptr(sites), _ptr(pos), B, rows, S, int(lower), int(upper),
+                                     None if rng is None else rng.data_ptr(), gn, gc, gu, int(first),
+                                     B if total is None else int(total), _stream()), "pgan_mono_switch")
 
     # ---------------- replay buffer / genotype sampling ----------------
     def fakebuf_step(self, buf_s, buf_p, state, slots, new_s, new_p, out_s, out_p, rng, picks=None):

@@ -7,10 +7,15 @@ Inside one iteration nothing touches the host: real batches come from a pool res
 in device memory, and the losses stay in device buffers until the caller reads them.
 
 Data parallel (one process per GPU, torch.distributed with the RCCL backend): every rank holds full
-replicas of both networks and optimiser states, draws its own batch / z / t, and the flat gradient
-buffers are all-reduced (mean) before each Adam step.  The generator's BatchNorm layers take their batch
+replicas of both networks and optimiser states, and the flat gradient buffers are summed over the ranks
+before each Adam step, which applies the 1 / ranks itself.  The generator's BatchNorm layers take their batch
 statistics over all ranks' samples (per-channel partial sums all-reduced inside forward and backward, the
 "global batch" of a single-device run) unless sync_bn=False keeps them per rank.
+With global_stream (the default on several ranks) the ranks split ONE run: every rank holds the whole pool and keeps
+the same generator states and pool cursor, which advance by the global batch, and rank r of P takes rows
+[r B/P, (r+1) B/P) of every real batch, z draw, t draw and augmentation draw -- P ranks at batch B/P then train on
+exactly the samples one device at batch B would (the weights agree up to the summation order of the all-reduce).
+Without it every rank draws from generator streams and a pool of its own.
 """
 from __future__ import annotations
 
@@ -27,9 +32,11 @@ class FusedTrainer:
     def __init__(self, ops, batch: int, device, loss: str = "gp", act: str = "sigmoid", lam: float = 10.0,
                  critic_iter: int = 5, seed: int = 1234, lr_d: float = 5e-5, lr_g: float = 5e-5,
                  latent: int = 128, process_group=None, rank: int = 0, world: int = 1, sync_bn: Optional[bool] = None,
-                 batched_generator: bool = True, data: int = 64):
-        """data: side of the square alignments, 64 (the reference's networks) or 128 (the scaled networks)."""
+                 batched_generator: bool = True, data: int = 64, global_stream: Optional[bool] = None):
+        """data: side of the square alignments, 64 (the reference's networks) or 128 (the scaled networks).
+        global_stream: the ranks take their rows of one global batch / draw (default on several ranks; see above)."""
         self.ops, self.dev, self.critic_iter = ops, torch.device(device), int(critic_iter)
+        self.global_stream = (world > 1) if global_stream is None else bool(global_stream)
         self.eng = Engine(ops, batch, device, loss=loss, act=act, lam=lam, latent=latent, lr_d=lr_d, lr_g=lr_g,
                           data=data)
         self.eng.use_device_step_counters()
@@ -64,10 +71,23 @@ class FusedTrainer:
         self.dist_active, self.sync_bn, self._drain = False, False, False
         if world > 1 or process_group is not None:
             self.attach_process_group(process_group, sync_bn)
-        # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks differ in the seed's high word
-        self.rng_z = torch.tensor([seed & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
-        self.rng_t = torch.tensor([(seed + 1) & 0x7FFFFFFF, rank, 0, 0], dtype=torch.int32, device=device)
+        # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks with streams of their own differ in the seed's
+        # high word, ranks that share one global stream hold identical states
+        self.seed = int(seed)
+        hi = 0 if self.global_stream else rank
+        self.stream_id = hi
+        self.rng_z = torch.tensor([seed & 0x7FFFFFFF, hi, 0, 0], dtype=torch.int32, device=device)
+        self.rng_t = torch.tensor([(seed + 1) & 0x7FFFFFFF, hi, 0, 0], dtype=torch.int32, device=device)
+        self.rng_aug = torch.tensor([(seed + 3) & 0x7FFFFFFF, hi, 0, 0], dtype=torch.int32, device=device)
+        self.rng_mono = torch.tensor([(seed + 4) & 0x7FFFFFFF, hi, 0, 0], dtype=torch.int32, device=device)
+        # this rank's rows of a global batch / draw: (first row, rows of the global batch)
+        self.row0, self.rows = (rank * self.eng.B, world * self.eng.B) if self.global_stream else (0, self.eng.B)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=device)
+        self.pool_normalized = False
+        self.label_noise: Optional[float] = None     # enable_augment
+        self.mono_bounds = None
+        self.aug_given = None                        # tests: (ey, (n, cols, u)) used instead of the device draws
+        self._pool_gen = None
         self.pool_s: Optional[torch.Tensor] = None
         self.pool_p: Optional[torch.Tensor] = None
         self.buf_s: Optional[torch.Tensor] = None    # replay buffer of generated alignments (enable_fake_buffer)
@@ -76,7 +96,7 @@ class FusedTrainer:
         self.cap_stream = None       # capture(): the stream the step graph is recorded on
         # generator-forwards-done mark of the batched iteration body (created here: nothing is created while a
         # tape or a graph is being recorded)
-        self.gen_done = torch.cuda.Event() if self.dev.type == "cuda" else False
+        self.gen_done = self._new_event()
         self.use_graph = False       # step(): capture on the first call, replay afterwards
         self.use_tape = False        # step(): record a launch tape on the first call, replay it afterwards
         self.iterations = 0
@@ -84,6 +104,17 @@ class FusedTrainer:
         # anything else that writes parameters in place must call weights_changed()
         if hasattr(ops, "static_weights"):
             ops.static_weights = True
+
+    def _new_event(self):
+        """An event of the library on the GPU (created up front, reused: see pgan_hip.Event), None on the host."""
+        if self.dev.type != "cuda":
+            return None
+        import pgan_hip
+        return pgan_hip.Event()
+
+    def _cur(self) -> int:
+        import pgan_hip
+        return pgan_hip._stream()
 
     def attach_process_group(self, process_group=None, sync_bn: Optional[bool] = None) -> None:
         """Switch on the data-parallel reductions over `process_group` (None: the default group once it exists).  A
@@ -93,6 +124,7 @@ class FusedTrainer:
         size) or over each rank's own samples (False: no collectives inside the generator)."""
         self.pg, self.dist_active = process_group, True
         self.tape = None
+        self.eng.grad_scale = 1.0 / self.world      # the gradient buffers hold sums over the ranks; Adam reads them scaled
         # Only RCCL reduces device memory in place, enqueued on the calling stream.  With any other backend (gloo: a
         # rehearsal of the data-parallel path on a box with one GPU) the trainer stages each collective through host
         # memory itself -- drain the device, copy out, reduce on the host, copy back -- instead of handing device
@@ -125,6 +157,7 @@ class FusedTrainer:
         self.pool_s = sites.to(self.dev, torch.float32).contiguous().clone()
         self.pool_p = pos.to(self.dev, torch.float32).contiguous().clone()
         self.graph = self.tape = None          # both hold the old pool's addresses
+        self.pool_normalized = bool(normalize)
         if normalize:
             self.ops.affine(self.pool_s, 2.0, -1.0, self.pool_s)
             self.ops.affine(self.pool_p, 2.0, -1.0, self.pool_p)
@@ -137,6 +170,7 @@ class FusedTrainer:
         assert bits.shape[0] == pos.shape[0] and bits.shape[0] >= self.eng.B
         self.pool_s, self.pool_p = alignment_slab.to_device(bits, pos, self.dev, normalize)
         self.graph = self.tape = None
+        self.pool_normalized = bool(normalize)
         self.cursor.zero_()
 
     def shuffle_pool(self, rows: bool = False) -> None:
@@ -145,12 +179,18 @@ class FusedTrainer:
         individuals of every alignment (np.random.shuffle(s), :257-258).  Device-side, outside
         the captured step."""
         n = self.pool_s.shape[0]
-        perm = torch.randperm(n, device=self.dev)
+        # a generator of the trainer's own, seeded like its device streams: ranks that split one run hold the whole pool
+        # and shuffle it the same way, and a run's sample order is a function of its seed alone
+        if self._pool_gen is None:
+            self._pool_gen = torch.Generator(device=self.dev)
+            self._pool_gen.manual_seed(self.seed + 5 + 1000003 * self.stream_id)
+        gen = self._pool_gen
+        perm = torch.randperm(n, device=self.dev, generator=gen)
         self.pool_s.copy_(self.pool_s[perm])
         self.pool_p.copy_(self.pool_p[perm])
         if rows:
             S = self.pool_s.shape[-1]
-            order = torch.rand(n, S, device=self.dev).argsort(dim=1)
+            order = torch.rand(n, S, device=self.dev, generator=gen).argsort(dim=1)
             idx = order.view(n, 1, S, 1).expand(n, 1, S, S)
             self.pool_s.copy_(torch.gather(self.pool_s, 2, idx))
         self.cursor.zero_()
@@ -172,6 +212,50 @@ class FusedTrainer:
         self.rng_buf = torch.tensor([seed & 0x7FFFFFFF, self.rank, 0, 0], dtype=torch.int32, device=self.dev)
         self.buf_picks = None
         self.graph = self.tape = None
+
+    def enable_augment(self, label_noise: Optional[float] = None, mono_switch=None) -> None:
+        """Per-batch augmentations of the real alignments, drawn afresh for every critic batch on the device inside the
+        recorded step.  label_noise: --label_smooth with this --label_noise (sites (1 - ey) + noise ey, ey ~ U(0, noise);
+        DataGeneratorDisk.get_batch, src/train_wgan_v2.py:265-268).  mono_switch: (lower, upper) bounds of
+        switch_monomorphic (:129-160; the reference's main passes 0, 10 at :523-524), applied after the smoothing and the
+        pool's normalisation, as the reference orders them."""
+        self.label_noise = None if label_noise is None else float(label_noise)
+        self.mono_bounds = None if mono_switch is None else (int(mono_switch[0]), int(mono_switch[1]))
+        self.graph = self.tape = None
+
+    def _take_real(self) -> None:
+        """The next real batch into the discriminator's input slots (this rank's rows of it), augmented; and the critic
+        step's interpolation draws."""
+        e, o, B = self.eng, self.ops, self.eng.B
+        S = e.data
+        slc = {} if not self.global_stream else {"offset": self.row0, "advance": self.rows}
+        o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor, **slc)
+        given = self.aug_given or (None, None)
+        if self.label_noise is not None:
+            o.label_smooth(e.X0[:B], self.label_noise, self.label_noise, self.pool_normalized, self.rng_aug, ey=given[0],
+                           skip=self.row0 * S * S, total=self.rows * S * S)
+        if self.mono_bounds is not None:
+            o.mono_switch(e.X0[:B], e.P0[:B], self.mono_bounds[0], self.mono_bounds[1], self.rng_mono, given=given[1],
+                          first=self.row0, total=self.rows)
+        if e.loss == "gp":
+            self._draw(e.tbuf, self.rng_t, False, 1)
+
+    def _draw(self, out: torch.Tensor, state: torch.Tensor, normal: bool, per_row: int) -> None:
+        """out = this rank's rows of a draw of per_row values for every row of the (global) batch."""
+        if self.global_stream:
+            self.ops.philox(out, state, normal, skip=self.row0 * per_row, total=self.rows * per_row)
+        else:
+            self.ops.philox(out, state, normal)
+
+    def _draw_z(self, Z: torch.Tensor) -> None:
+        """Latent draws of one or several consecutive generator passes (Z: [passes B, latent]) in the reference's order:
+        one draw per pass over the global batch."""
+        B = self.eng.B
+        if not self.global_stream:
+            self.ops.philox(Z, self.rng_z, True)      # one long draw equals the passes' separate draws
+            return
+        for i in range(Z.shape[0] // B):
+            self._draw(Z[i * B:(i + 1) * B], self.rng_z, True, self.eng.latent)
 
     def _hand_fakes(self, src_s: torch.Tensor, src_p: torch.Tensor) -> None:
         """This critic step's fake batch into the discriminator's input slots: the fresh fakes themselves, or (replay
@@ -228,7 +312,7 @@ class FusedTrainer:
                 # process group's own stream, whose hand-over costs ~30 us of idle queue per call.  The 1-D towers'
                 # stream is idle by now and is joined at the end of the pass, so the bucket is reduced there, beside
                 # the rest of the backward pass.
-                side.wait_stream(torch.cuda.current_stream())
+                self.eng.side.ev_fork.edge(self._cur(), side.cuda_stream)
                 with torch.cuda.stream(side):
                     work = self._sum_over_ranks(store.gflat[lo:hi])
             self._early.append((store, (lo, hi), work))
@@ -236,8 +320,9 @@ class FusedTrainer:
     _early_reduce_g = _early_reduce
 
     def _allreduce(self, flat: torch.Tensor) -> None:
-        """Sum `flat` (a store's whole gradient buffer) over the ranks and divide by their number; ranges whose
-        reduction was already started by _early_reduce are only waited for."""
+        """Sum `flat` (a store's whole gradient buffer) over the ranks; ranges whose reduction was already started by
+        _early_reduce are only waited for.  The division by the number of ranks happens inside the Adam step that
+        follows (Engine.grad_scale): no separate pass over the buffer."""
         if not self.dist_active:
             return
         store = self.eng.D if flat.data_ptr() == self.eng.D.gflat.data_ptr() else self.eng.G
@@ -255,8 +340,6 @@ class FusedTrainer:
             self._early = [e for e in self._early if e[0] is not store]
         else:
             self._sum_over_ranks(flat)
-        if self.world > 1:
-            self.ops.affine(flat, 1.0 / self.world, 0.0, flat)
 
     def _iteration_body(self) -> None:
         if self.batched_generator:
@@ -277,18 +360,16 @@ class FusedTrainer:
         m = n + 1
         gs.fork()
         with gs:
-            o.philox(e.Zw[:B], self.rng_z, True)
+            self._draw_z(e.Zw[:B])
             e.gen_forward_chunks(0, 1)
 
         def step_inputs(i):
             """Critic step i's real batch, interpolation draws and fakes into the discriminator's input slots."""
-            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
-            if e.loss == "gp":
-                o.philox(e.tbuf, self.rng_t, False)
+            self._take_real()
             if i == 0:
                 gs.join()
             elif i == 1 and self.gen_done:
-                pgan_tape.call(torch.cuda.current_stream().wait_event, self.gen_done)
+                self.gen_done.wait(self._cur())
             self._hand_fakes(e.fake_s[i * B:(i + 1) * B], e.fake_p[i * B:(i + 1) * B])
 
         # A critic step ends in a serial run of small launches (gradient reductions, Adam, weight preparation) and used to
@@ -301,10 +382,10 @@ class FusedTrainer:
             if i == 0:
                 gs.fork()
                 with gs:
-                    o.philox(e.Zw[B:m * B], self.rng_z, True)
+                    self._draw_z(e.Zw[B:m * B])
                     e.gen_forward_chunks(1, m)
                     if self.gen_done:
-                        pgan_tape.call(self.gen_done.record, gs.stream)
+                        self.gen_done.record(gs.raw)
             e.critic_grads_resident(run_generator=False)
             if ahead and i + 1 < n:
                 e.side.fork()
@@ -334,22 +415,20 @@ class FusedTrainer:
             S = e.data
             self.fa_s = [torch.zeros(B, 1, S, S, device=self.dev) for _ in range(n)]
             self.fa_p = [torch.zeros(B, 1, S, device=self.dev) for _ in range(n)]
-            self.fa_done = [torch.cuda.Event() if self.dev.type == "cuda" else None for _ in range(n)]
+            self.fa_done = [self._new_event() for _ in range(n)]
         gs.fork()
         with gs:
             for i in range(n):
-                o.philox(e.Z, self.rng_z, True)
+                self._draw_z(e.Z)
                 e.gen_forward_resident(self.fa_s[i], self.fa_p[i])
                 if self.fa_done[i] is not None:
-                    pgan_tape.call(self.fa_done[i].record, gs.stream)
-            o.philox(e.Z, self.rng_z, True)
+                    self.fa_done[i].record(gs.raw)
+            self._draw_z(e.Z)
             e.gen_forward_resident(e.gXs, e.gXp)       # its activations stay in the workspace for the generator step
         for i in range(n):
-            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
-            if e.loss == "gp":
-                o.philox(e.tbuf, self.rng_t, False)
+            self._take_real()
             if self.fa_done[i] is not None:       # this step's fakes are complete
-                pgan_tape.call(torch.cuda.current_stream().wait_event, self.fa_done[i])
+                self.fa_done[i].wait(self._cur())
             self._hand_fakes(self.fa_s[i], self.fa_p[i])
             e.critic_grads_resident(run_generator=False)
             self._reduce(e.D.gflat)
@@ -372,17 +451,15 @@ class FusedTrainer:
             self.fk_p = [torch.zeros(B, 1, S, device=self.dev) for _ in range(2)]
         gs.fork()
         with gs:
-            o.philox(e.Z, self.rng_z, True)
+            self._draw_z(e.Z)
             e.gen_forward_resident(self.fk_s[0], self.fk_p[0])
         for i in range(self.critic_iter):
-            o.take_batch(self.pool_s, self.pool_p, e.X0[:B], e.P0[:B], self.cursor)
-            if e.loss == "gp":
-                o.philox(e.tbuf, self.rng_t, False)
+            self._take_real()
             gs.join()                                   # this step's fakes are complete
             self._hand_fakes(self.fk_s[i & 1], self.fk_p[i & 1])
             gs.fork()
             with gs:                                    # next forward, beside this critic step
-                o.philox(e.Z, self.rng_z, True)
+                self._draw_z(e.Z)
                 if i + 1 < self.critic_iter:
                     e.gen_forward_resident(self.fk_s[(i + 1) & 1], self.fk_p[(i + 1) & 1])
                 else:
@@ -406,7 +483,8 @@ class FusedTrainer:
         lazily created object of an iteration (per-stream scratch, prepared weight planes, events, variant buffers)
         exists before the capture opens; inside it nothing may allocate (checked: the op backend refuses, and the
         allocator's request count must not move).  The capture goes through the library's own entry points
-        (pgan_step_graph_begin / _end), not through torch's graph machinery."""
+        (pgan_step_graph_begin / _end), not through torch's graph machinery, and every cross-stream edge inside it is a
+        record / wait on an event of the library that existed before (checked: pgan_events_created must not move)."""
         if self.dist_active:
             raise RuntimeError("graph capture is used on the single-GPU path only")
         from pgan_hip import StepGraph
@@ -424,7 +502,11 @@ class FusedTrainer:
         self.iterations += 1
         tracked, dstep, gstep = self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step
         self.ops.invalidate_weight_planes()      # so that the recorded iteration starts by preparing them
+        with torch.cuda.stream(cap):
+            self.ops.settle_weight_planes()      # ... and holds no reset of the running weight maxima
+        import pgan_hip
         requests = torch.cuda.memory_stats(self.dev).get("allocation.all.allocated", 0)
+        events = pgan_hip.events_created()
         graph = StepGraph()
         self.ops.capturing = True
         try:
@@ -437,6 +519,8 @@ class FusedTrainer:
             self.eng.g_batches_tracked, self.eng.D.step, self.eng.G.step = tracked, dstep, gstep
         if torch.cuda.memory_stats(self.dev).get("allocation.all.allocated", 0) != requests:
             raise RuntimeError("device memory was requested while the step graph was being captured")
+        if pgan_hip.events_created() != events:
+            raise RuntimeError("an event was created while the step graph was being captured")
         self.graph = graph
 
     def record_tape(self) -> None:
@@ -451,16 +535,21 @@ class FusedTrainer:
         # the planes of old weights while Adam keeps stepping the fp32 ones
         if hasattr(self.ops, "invalidate_weight_planes"):
             self.ops.invalidate_weight_planes()
+            self.ops.settle_weight_planes()      # pending resets of the weight maxima happen now, not in every replay
         pgan_tape.tape = entries = []
         try:
             self._iteration_body()
         finally:
             pgan_tape.tape = None
         self.iterations += 1
-        self.tape = entries
+        # replay form: runs of library calls as native tapes walked in C (PGAN_NATIVE_TAPE=0: call by call from Python)
+        self.tape = pgan_tape.compile(entries) if os.environ.get("PGAN_NATIVE_TAPE", "1") != "0" else entries
 
     def replay_tape(self) -> None:
-        pgan_tape.replay(self.tape)
+        if isinstance(self.tape, list):
+            pgan_tape.replay(self.tape)
+        else:
+            self.tape.replay()
         self.iterations += 1
         self.eng.g_batches_tracked += self.critic_iter + 1
         self.eng.D.step += self.critic_iter

@@ -10,7 +10,12 @@ Differences from the reference, all deliberate:
     np.loadtxt, no per-iteration host synchronisation: losses are read back only when logged);
   * flags the reference parses but never reads are live: --gen (sigGen | tanGen | tanNorm),
     --use_buffer/--buffer_n (replay buffer of generated alignments, :98-117), --permute /
-    --shuffle_inds (row shuffle of each real alignment), --label_smooth/--label_noise;
+    --shuffle_inds (row shuffle of each real alignment), --label_smooth/--label_noise (fresh noise for every
+    critic batch, as DataGeneratorDisk.get_batch draws it, :265-268); --mono_switch (live in the reference, :523-524)
+    is drawn per critic batch on the device as well;
+  * several GPUs (python -m torch.distributed.run --nproc-per-node N train_wgan_v2.py ...): --batch_size stays the
+    global batch and the ranks split one run -- same pool, same generator streams, rank r takes rows
+    [r B/N, (r+1) B/N) of every batch and draw -- so N GPUs train on the samples one GPU at that batch would;
   * an "epoch" is floor(num_in / batch / critic_iter) full iterations (the reference's extra
     generator step on the exhausted loader, :531-532,:639-640, is not reproduced);
   * of the --plot outputs (matplotlib / scikit-allel figures) only the 2DSWD number (w_dist_pca.txt) is produced.
@@ -223,22 +228,32 @@ def switch_monomorphic(sites, positions, lower_bound, upper_bound):
     return sites, positions
 
 
-_GENOTYPE_RNG = {}
+_GENOTYPE_RNG = {}        # device -> (op backend, Philox state): one per process and device
+GENOTYPE_SEED = 20260     # seed of the device sampler's generator; set_genotype_sampler replaces it
+
+
+def set_genotype_sampler(ops, seed: int) -> None:
+    """Use `ops` (the trainer's op backend) and a generator state seeded with `seed` for the device path of
+    sample_genotypes_bernoulli on that backend's GPU.  Without this call the first use builds a small backend of its
+    own, seeded with GENOTYPE_SEED; Python's `random` stream is never touched."""
+    dev = torch.device(ops.device)
+    _GENOTYPE_RNG[dev] = (ops, torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF, 0, 0], dtype=torch.int32,
+                                            device=dev))
 
 
 def sample_genotypes_bernoulli(sites_tensor, require_variation=True):
     """src/train_wgan_v2.py:162-192: Bernoulli genotypes from the generator's probabilities; a column
     that came out monomorphic is redrawn and one individual, picked in proportion to its probability
-    of carrying the missing allele, is set to it.  Tensors on the GPU are sampled there by one kernel
-    (pgan_sample_genotypes, device Philox seeded from Python's `random`); host tensors by the loop below."""
-    if sites_tensor.is_cuda:
+    of carrying the missing allele, is set to it.  Tensors on the GPU with 64 or 128 individuals are sampled there by one
+    kernel (pgan_sample_genotypes, device Philox: see set_genotype_sampler); everything else by the loop below."""
+    if sites_tensor.is_cuda and sites_tensor.dim() == 4 and sites_tensor.shape[1] == 1 and sites_tensor.shape[2] in (64, 128):
         from pgan_hip import HipOps
         dev = sites_tensor.device
         ent = _GENOTYPE_RNG.get(dev)
         if ent is None:
-            ent = _GENOTYPE_RNG[dev] = (HipOps(dev, ws_floats=4, max_samples=1),
-                                        torch.tensor([random.randrange(1 << 31), random.randrange(1 << 31), 0, 0],
-                                                     dtype=torch.int32, device=dev))
+            with torch.cuda.device(dev):
+                set_genotype_sampler(HipOps(dev, ws_floats=4, max_samples=1), GENOTYPE_SEED)
+            ent = _GENOTYPE_RNG[dev]
         p = sites_tensor.detach().to(torch.float32).contiguous()
         out = torch.empty_like(p)
         with torch.cuda.device(dev):
@@ -406,7 +421,7 @@ def main(argv=None):
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     # several GPUs (python -m torch.distributed.run --nproc-per-node N train_wgan_v2.py ...): --batch_size stays
-    # the global batch, split evenly; every rank reads the same files and trains on every world-th alignment
+    # the global batch, split evenly; every rank reads the same files and takes its rows of every global batch
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:
         if batch % world:
@@ -436,20 +451,17 @@ def main(argv=None):
     if bits is not None:
         sites = torch.from_numpy(alignment_slab.unpack_numpy(bits)[:, None])
         pos = torch.from_numpy(pos64[:, None].copy())
+    seed = random.randrange(1 << 30)      # drawn while the ranks' generators agree: one seed for all of them
     if world > 1:
         random.seed()
-    if args.mono_switch or args.label_smooth:
-        bits = None                       # host-side float transforms follow: the pool is set from the fp32 tensors
-    if args.mono_switch:
-        sites, pos = switch_monomorphic(sites, pos, 0, 10)
-    if args.label_smooth:
-        hi = float(args.label_noise)
-        ey = torch.from_numpy(np.random.uniform(0.0, hi, tuple(sites.shape)).astype(np.float32))
-        sites = sites * (1 - ey) + hi * ey
     trainer = FusedTrainer(HipOps(dev), batch, dev, loss=args.loss, act=act, lam=lam, critic_iter=critic_iter,
-                           seed=random.randrange(1 << 30), lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
+                           seed=seed, lr_d=float(args.disc_lr), lr_g=float(args.gen_lr),
                            latent=latent, rank=rank, world=world, sync_bn=(not args.local_bn) if world > 1 else None,
                            data=data_size)
+    # --label_smooth / --mono_switch: drawn afresh for every critic batch, on the device, inside the recorded step
+    if args.label_smooth or args.mono_switch:
+        trainer.enable_augment(label_noise=float(args.label_noise) if args.label_smooth else None,
+                               mono_switch=(0, 10) if args.mono_switch else None)
     if world > 1:      # after the trainer, whose streams then hold the hardware queues ahead of the collective library's
         import torch.distributed as dist
         backend = os.environ.get("PGAN_DIST_BACKEND", "nccl")
@@ -463,7 +475,7 @@ def main(argv=None):
     else:
         default_init(trainer.eng.G)
         default_init(trainer.eng.D)
-    if world > 1:                      # rank 0's initial weights everywhere; disjoint shares of the input
+    if world > 1:                      # rank 0's initial weights everywhere
         import torch.distributed as dist
         for flat in (trainer.eng.G.flat, trainer.eng.D.flat):
             if dist.get_backend() == "nccl":
@@ -473,12 +485,13 @@ def main(argv=None):
                 dist.broadcast(host, src=0)
                 flat.copy_(host)
     trainer.weights_changed()
-    if bits is not None:
-        trainer.set_pool_packed(bits[rank::world], pos64[rank::world], normalize=normalize)
+    if bits is not None:               # every rank holds the whole pool (the ranks take their rows of each global batch)
+        trainer.set_pool_packed(bits, pos64, normalize=normalize)
     else:
-        trainer.set_pool(sites[rank::world], pos[rank::world], normalize=normalize)
+        trainer.set_pool(sites, pos, normalize=normalize)
     if args.use_buffer:
         trainer.enable_fake_buffer(int(args.buffer_n) * batch)
+    set_genotype_sampler(trainer.ops, seed + 6)     # the checkpoints' genotyping pass shares the trainer's backend
     trainer.use_tape = True      # first iteration recorded as a launch tape, the rest replayed (one or several GPUs)
 
     iters_per_epoch = max(1, (num_in // (batch * world)) // critic_iter)

@@ -43,7 +43,9 @@ def _worker(rank, world, port, loss, B, out_dir):
     loss_part = tr.eng.closs.clone()
     dist.all_reduce(loss_part)
     if rank == 0:
-        torch.save({"g": tr.eng.D.gflat.clone(), "loss": loss_part / world}, os.path.join(out_dir, "dp.pt"))
+        # _allreduce leaves the SUM over the ranks; the Adam step that follows reads it times Engine.grad_scale
+        assert tr.eng.grad_scale == 1.0 / world
+        torch.save({"g": tr.eng.D.gflat * tr.eng.grad_scale, "loss": loss_part / world}, os.path.join(out_dir, "dp.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,7 +86,7 @@ def _gen_worker(rank, world, port, B, out_dir):
     loss_part = tr.eng.gloss.clone()
     dist.all_reduce(loss_part)
     if rank == 1:     # the other rank holds the same reduced gradients and running statistics
-        torch.save({"g": tr.eng.G.gflat.clone(), "loss": loss_part / world,
+        torch.save({"g": tr.eng.G.gflat * tr.eng.grad_scale, "loss": loss_part / world,
                     "buf": {k: v.clone() for k, v in tr.eng.Gbuf.p.items()}}, os.path.join(out_dir, "dpg.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -122,7 +124,7 @@ def _iter_worker(rank, world, port, sync_bn, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     tr = FusedTrainer(TorchOps(), 2, torch.device("cpu"), critic_iter=2, process_group=dist.group.WORLD, rank=rank,
-                      world=world, sync_bn=sync_bn)
+                      world=world, sync_bn=sync_bn, global_stream=False)
     tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
     tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
     rs, rp = orc.synthetic_alignments(16, 70)
@@ -152,3 +154,81 @@ def test_two_rank_iterations_keep_the_replicas_identical(tmp_path, sync_bn):
     assert same == sync_bn
     d0 = torch.cat([v.reshape(-1) for v in orc.make_params(orc.disc_param_shapes(), 7).values()])
     assert float(a["d"].abs().sum()) != float(d0.abs().sum())
+
+
+def _split_run_worker(rank, world, port, loss, B, steps, out_dir):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_trainer import FusedTrainer
+    from torch_ops import TorchOps
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = _split_run_trainer(FusedTrainer, TorchOps, loss, B // world, rank, world, dist.group.WORLD)
+    assert tr.global_stream and tr.sync_bn
+    for _ in range(steps):
+        tr.step()
+    e = tr.eng
+    torch.save({"g": e.G.flat.clone(), "d": e.D.flat.clone(), "losses": tr.losses(),
+                "buf": {k: v.clone() for k, v in e.Gbuf.p.items()},
+                # this rank's latent and interpolation draws of the last steps; the state its next inputs come from
+                "Zw": e.Zw.clone(), "t": e.tbuf.clone(), "pool": tr.pool_s.clone(), "cursor": tr.cursor.clone(),
+                "rng": torch.stack([tr.rng_z, tr.rng_t, tr.rng_aug, tr.rng_mono])},
+               os.path.join(out_dir, f"split{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _split_run_trainer(FusedTrainer, TorchOps, loss, batch, rank, world, pg):
+    tr = FusedTrainer(TorchOps(), batch, torch.device("cpu"), loss=loss, critic_iter=2, seed=99, process_group=pg,
+                      rank=rank, world=world)
+    tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    rs, rp = orc.synthetic_alignments(24, 70)
+    tr.set_pool(rs, rp)                      # every rank holds the whole pool
+    tr.enable_augment(label_noise=0.05, mono_switch=(0, 10))
+    tr.shuffle_pool(rows=True)
+    return tr
+
+
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_two_ranks_split_one_run_sample_for_sample(tmp_path, loss):
+    """step() itself on two ranks equals step() of one process at the whole batch: the ranks keep one pool cursor and
+    one set of generator streams (z, t, label-smoothing noise, monomorphic-site draws, pool shuffles) and take rows
+    [r B/P, (r+1) B/P) of every batch and draw; the generator's BatchNorm statistics run over the global batch.  Three
+    iterations of 2 critic steps + 1 generator step.  The inputs of the last steps are bit-identical; the weights agree
+    up to the summation order of the reductions (1e-5 of their norm after Adam's near-sign first steps, a thousandth of
+    the distance travelled).  The one-process run takes its BatchNorm statistics through the same sums / apply pair as
+    the ranks do (a no-op reduction): the one-launch form rounds the statistics differently in the last bit, which is
+    enough to put a pre-activation on the other side of a LeakyReLU kink now and then."""
+    from pgan_trainer import FusedTrainer
+    from torch_ops import TorchOps
+    B, steps = 4, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_split_run_worker, args=(2, port, loss, B, steps, str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"split{r}.pt", weights_only=True) for r in (0, 1))
+    assert torch.equal(a["g"], b["g"]) and torch.equal(a["d"], b["d"])
+    one = _split_run_trainer(FusedTrainer, TorchOps, loss, B, 0, 1, None)
+    assert not one.global_stream and not one.dist_active
+    one.eng.bn_sync = lambda part: None
+    start = {"g": one.eng.G.flat.clone(), "d": one.eng.D.flat.clone()}
+    for _ in range(steps):
+        one.step()
+    e, h = one.eng, B // 2
+    rows = lambda t, per: torch.cat([x.reshape(-1, h, per) for x in t], dim=1)      # ranks' rows side by side
+    assert torch.equal(rows((a["Zw"], b["Zw"]), 128), e.Zw.reshape(-1, B, 128))
+    if loss == "gp":
+        assert torch.equal(rows((a["t"], b["t"]), 1), e.tbuf.reshape(1, B, 1))
+    for r in (a, b):      # same shuffled pool, same cursor, same generator states on every rank as in the one process
+        assert torch.equal(r["pool"], one.pool_s) and torch.equal(r["cursor"], one.cursor)
+        assert torch.equal(r["rng"], torch.stack([one.rng_z, one.rng_t, one.rng_aug, one.rng_mono]))
+    for key, got, ref in (("g", a["g"], e.G.flat), ("d", a["d"], e.D.flat)):
+        err = float((got - ref).norm() / ref.norm())
+        moved = float((ref - start[key]).norm() / ref.norm())
+        assert moved > 1e-3 and err <= 1e-5 and err <= 2e-3 * moved, (key, err, moved)
+    for k, v in one.eng.Gbuf.p.items():
+        assert torch.allclose(a["buf"][k], v, rtol=1e-4, atol=1e-5), k
+    # every loss term is a batch mean: the ranks' values average to the one process's
+    assert np.allclose((np.array(a["losses"]) + np.array(b["losses"])) / 2, one.losses(), rtol=1e-4, atol=1e-5)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -37,6 +38,85 @@ def _put_channel_amax(amax, out):
     """BatchNorm ops: amax[c] = largest magnitude of channel c of the op's output."""
     if amax is not None:
         amax.copy_(out.abs().amax([d for d in range(out.dim()) if d != 1]).to(amax.dtype))
+
+
+def philox_words(state, first_call: int, ncalls: int) -> np.ndarray:
+    """Philox4x32-10 as the device generator runs it: call number (state offset + first_call + i) under the key
+    (state[0], state[1]) gives four 32-bit words; returns uint32 [ncalls, 4].  state: 4 integers."""
+    st = [int(x) & 0xFFFFFFFF for x in state]
+    off = ((st[3] << 32) | st[2]) + int(first_call)
+    ctr = (np.uint64(off) + np.arange(ncalls, dtype=np.uint64))
+    c = [(ctr & np.uint64(0xFFFFFFFF)), (ctr >> np.uint64(32)), np.zeros(ncalls, np.uint64), np.zeros(ncalls, np.uint64)]
+    k0, k1 = st[0], st[1]
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def philox_advance(state, calls: int) -> None:
+    """state's 64-bit offset += calls (state: an int32 tensor of 4 words, as the trainer keeps it)."""
+    off = (((int(state[3]) & 0xFFFFFFFF) << 32) | (int(state[2]) & 0xFFFFFFFF)) + int(calls)
+    lo, hi = off & 0xFFFFFFFF, (off >> 32) & 0xFFFFFFFF
+    state[2] = lo - (1 << 32) if lo >= (1 << 31) else lo
+    state[3] = hi - (1 << 32) if hi >= (1 << 31) else hi
+
+
+def philox_values(state, skip: int, n: int, normal: bool) -> np.ndarray:
+    """Values [skip, skip + n) of the draw that starts at the state's offset, as pgan_philox_slice produces them:
+    uniforms (word >> 8) 2^-24; normals by Box-Muller on the word pairs of a call, in float32."""
+    g0, g1 = skip // 4, (skip + n + 3) // 4
+    w = philox_words(state, g0, g1 - g0)
+    if normal:
+        u1 = ((w[:, 0::2] >> 8).astype(np.float32) + np.float32(1)) * np.float32(2.0 ** -24)
+        u2 = (w[:, 1::2] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+        rad = np.sqrt(np.float32(-2) * np.log(u1, dtype=np.float32), dtype=np.float32)
+        ang = np.float32(6.28318530717958647692) * u2
+        v = np.stack([rad * np.cos(ang, dtype=np.float32), rad * np.sin(ang, dtype=np.float32)], axis=2).reshape(-1, 4)
+    else:
+        v = (w >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+    return v.reshape(-1)[skip - 4 * g0: skip - 4 * g0 + n].astype(np.float32)
+
+
+MONO_CALLS, MONO_MAX = 8, 15      # Philox calls reserved per alignment / most columns switched (pgan_mono_switch)
+
+
+def mono_switch_draws(state, first: int, B: int, lower: int, upper: int, S: int):
+    """The draws pgan_mono_switch makes for alignments first .. first + B - 1: (n [B], cols [B, upper], u [B, upper])."""
+    n_out = np.zeros(B, np.int32)
+    cols = np.zeros((B, upper), np.int32)
+    us = np.zeros((B, upper), np.float32)
+    for a in range(B):
+        w = philox_words(state, (first + a) * MONO_CALLS, MONO_CALLS).reshape(-1).astype(np.uint64)
+        n = lower + int((w[0] * np.uint64(upper - lower + 1)) >> np.uint64(32))
+        perm = list(range(S))
+        for k in range(n):
+            j = k + int((w[1 + k] * np.uint64(S - k)) >> np.uint64(32))
+            perm[j], perm[k] = perm[k], perm[j]
+            cols[a, k] = perm[k]
+            us[a, k] = np.float32(int(w[1 + MONO_MAX + k]) >> 8) * np.float32(2.0 ** -24)
+        n_out[a] = n
+    return n_out, cols, us
+
+
+def mono_switch_apply(sites, pos, n, cols, u):
+    """switch_monomorphic (/root/reference/src/train_wgan_v2.py:129-160) with its draws given: per alignment the first
+    n // 2 chosen columns all 0, the rest all 1; each chosen column's position redrawn, in the order drawn, as
+    lo + (hi - lo) u between its current neighbours (0 / 1 at the ends), in double precision like np.random.uniform."""
+    S = sites.shape[3]
+    for a in range(sites.shape[0]):
+        k_n = int(n[a])
+        c = [int(x) for x in cols[a][:k_n]]
+        for k, i in enumerate(c):
+            sites[a, :, :, i] = 0.0 if k < k_n // 2 else 1.0
+        for k, i in enumerate(c):
+            lo = 0.0 if i == 0 else float(pos[a, 0, i - 1])
+            hi = 1.0 if i == S - 1 else float(pos[a, 0, i + 1])
+            pos[a, :, i] = float(lo + (hi - lo) * float(u[a][k]))
+    return sites, pos
 
 
 class TorchOps:
@@ -331,30 +411,56 @@ class TorchOps:
         dw.copy_(torch.nn.grad.conv1d_weight(x, dw.shape, ya, stride=2, padding=1))
 
     # ---------------- optimiser / misc ----------------
-    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None):
+    def adam(self, p, g, m, v, step, lr, b1, b2, eps, step_dev=None, grad_scale=1.0):
         if step_dev is not None:      # step count kept in a tensor: incremented, then used
             step_dev += 1
             step = int(step_dev)
+        if grad_scale != 1.0:
+            g = g * grad_scale
         bc1 = 1.0 - b1 ** step
         bc2 = 1.0 - b2 ** step
         m.mul_(b1).add_(g, alpha=1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
 
-    def philox(self, out, state, normal):
-        """Stand-in for the device generator (same interface, not the same numbers): values are a function of the
-        4-word state, whose offset words advance by the number of 4-value groups drawn."""
-        g = torch.Generator().manual_seed(int(state[0]) + 7919 * int(state[1]) + 104729 * int(state[2]))
-        v = torch.randn(out.shape, generator=g) if normal else torch.rand(out.shape, generator=g)
-        out.copy_(v)
-        state[2] += (out.numel() + 3) // 4
+    def philox(self, out, state, normal, skip=0, total=None):
+        """The device generator restated (Philox4x32-10, same words, same conversions): values [skip, skip + n) of a draw
+        of `total`, the state's offset advanced by the whole draw."""
+        n = out.numel()
+        total = n if total is None else total
+        out.copy_(torch.from_numpy(philox_values(state.tolist(), skip, n, bool(normal))).reshape(out.shape))
+        philox_advance(state, (total + 3) // 4)
 
-    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor):
+    def take_batch(self, pool_s, pool_p, out_s, out_p, cursor, offset=0, advance=None):
         n, B = pool_s.shape[0], out_s.shape[0]
-        idx = (int(cursor) + torch.arange(B)) % n
+        idx = (int(cursor) + offset + torch.arange(B)) % n
         out_s.copy_(pool_s[idx])
         out_p.copy_(pool_p[idx])
-        cursor.copy_((cursor + B) % n)
+        cursor.copy_((cursor + (B if advance is None else advance)) % n)
+
+    def label_smooth(self, sites, noise, centre, normalized, rng, ey=None, skip=0, total=None):
+        """sites (1 - ey) + centre ey on the raw values (DataGeneratorDisk.get_batch,
+        /root/reference/src/train_wgan_v2.py:265-268), ey = noise * uniform from the device generator's words."""
+        n = sites.numel()
+        total = n if total is None else total
+        if ey is None:
+            e = torch.from_numpy(philox_values(rng.tolist(), skip, n, False)).reshape(sites.shape) * noise
+            philox_advance(rng, (total + 3) // 4)
+        else:
+            e = ey.reshape(sites.shape)
+        raw = sites * 0.5 + 0.5 if normalized else sites
+        sm = raw * (1 - e) + centre * e
+        sites.copy_(sm * 2 - 1 if normalized else sm)
+
+    def mono_switch(self, sites, pos, lower, upper, rng, given=None, first=0, total=None):
+        B, S = sites.shape[0], sites.shape[3]
+        total = B if total is None else total
+        if given is None:
+            n, cols, u = mono_switch_draws(rng.tolist(), first, B, lower, upper, S)
+            philox_advance(rng, total * MONO_CALLS)
+        else:
+            n, cols, u = (t.cpu().numpy().reshape(B, -1) if i else t.cpu().numpy() for i, t in enumerate(given))
+        mono_switch_apply(sites, pos, n, cols, u)
 
     def affine(self, x, scale, shift, out):
         out.copy_(x * scale + shift)
