@@ -140,9 +140,12 @@ int pgan_gn_fwd_presummed(const float* a, const float* gamma, const float* beta,
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result as pgan_gn_fwd; the
  * slice partial sums live in a fixed array inside the library (384 KiB per GPU, for up to
  * pgan_gn_fwd_static_max_samples() = 2048 samples per call; more returns -3 and launches nothing).  Calls no hipMalloc /
- * hipFree.  All calls on one GPU share that array: calls that overlap there (different streams) race. */
+ * hipFree.  All calls on one GPU share that array: calls that overlap there (different streams) race.  The array's
+ * address on the stream's device is looked up at the first call there; a first call whose stream is being captured is
+ * refused (-1) instead -- pgan_gn_fwd_static_init() does the lookup for the current device ahead of time. */
 int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C,
                        int HW, hipStream_t st);
+int pgan_gn_fwd_static_init(void);
 int pgan_gn_fwd_static_max_samples(void);
 /* first-order backward (autograd through GroupNorm/LeakyReLU): d = dL/da from u = dL/dh;
  * stats_b = (mean w, mean w*xhat), w = gamma*m*u; pg/pb = per-sample sums for dL/dgamma, dL/dbeta.

@@ -688,18 +688,46 @@ int pgan_gn_fwd_presummed(const float* a, const float* gamma, const float* beta,
 // device, with that device current, and kept.  Every partial sum that the apply launch reads is written by the sums
 // launch of the same call, so nothing needs clearing between calls; two calls that overlap on one GPU (different
 // streams) share the array and race.
-int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C,
-                       int HW, hipStream_t st) {
-    if (N > GN_STATIC_MAX_N) return PGAN_ELIMIT;
+// Address of `scratch` on the device that owns stream st (the current device for the null stream), looked up once per
+// device and kept.  The lookup is a runtime call that may load the code object: it must not happen while st is being
+// captured, so a first use under capture is refused (PGAN_EINVAL) -- call pgan_gn_fwd_static_init beforehand.
+static int static_scratch_of(hipStream_t st, double** out) {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return PGAN_ELAUNCH;
+    hipDevice_t sdev;
+    if (st && hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;
+    else if (hipGetDevice(&dev) != hipSuccess) return PGAN_ELAUNCH;
+    if (dev < 0 || dev >= MAX_DEVICES) return PGAN_ELAUNCH;
     double* w = g_scratch_ptr[dev].load(std::memory_order_acquire);
     if (!w) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return PGAN_EINVAL;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return PGAN_ELAUNCH;
+        if (cur != dev && hipSetDevice(dev) != hipSuccess) return PGAN_ELAUNCH;       // each GPU has its own copy
         void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PGAN_ELAUNCH;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (e != hipSuccess || !p) return PGAN_ELAUNCH;
         w = static_cast<double*>(p);
         g_scratch_ptr[dev].store(w, std::memory_order_release);
     }
+    *out = w;
+    return PGAN_OK;
+}
+
+// Looks the array's address up for the current device now, outside any capture (optional: the first
+// pgan_gn_fwd_static call on a device does it too, unless its stream is being captured).
+int pgan_gn_fwd_static_init(void) {
+    double* w = nullptr;
+    return static_scratch_of(nullptr, &w);
+}
+
+int pgan_gn_fwd_static(const float* a, const float* gamma, const float* beta, float* h, float* stats, int N, int C,
+                       int HW, hipStream_t st) {
+    if (N > GN_STATIC_MAX_N) return PGAN_ELIMIT;
+    double* w = nullptr;
+    const int rc = static_scratch_of(st, &w);
+    if (rc != PGAN_OK) return rc;
     if (!gn_shape_ok(N, C, HW, w, (long long)sizeof(double) * GN_STATIC_MAX_N * SL * 3)) return PGAN_EINVAL;
     gn_fwd_sums<<<N * SL, ST, 0, st>>>(a, w, C * HW, C);
     gn_fwd_apply<<<N * SL, ST, 0, st>>>(a, gamma, beta, h, stats, w, C * HW, HW, C, nullptr);

@@ -124,7 +124,7 @@ EXPORTS = sorted(list(_SIGS) + ["pgan_conv_wgrad_workspace_floats", "pgan_set_op
                                 "pgan_conv_h2_prep_bytes", "pgan_conv_wgrad_h2_workspace_floats",
                                 "pgan_gn_workspace_bytes", "pgan_bn_workspace_bytes", "pgan_bn_partials",
                                 "pgan_bn_fwd_partials", "pgan_gn_fwd_static_max_samples", "pgan_build_info",
-                                "pgan_events_created", "pgan_tape_create", "pgan_tape_entry_name"])
+                                "pgan_events_created", "pgan_tape_create", "pgan_tape_entry_name", "pgan_gn_fwd_static_init"])
 for _name, _args in _SIGS.items():
     _fn = getattr(_lib, _name)
     _fn.argtypes = _args
@@ -139,6 +139,8 @@ _lib.pgan_bn_fwd_partials.argtypes = [I, I, I, I]
 _lib.pgan_bn_fwd_partials.restype = c_longlong
 _lib.pgan_gn_fwd_static_max_samples.argtypes = []
 _lib.pgan_gn_fwd_static_max_samples.restype = c_int
+_lib.pgan_gn_fwd_static_init.argtypes = []
+_lib.pgan_gn_fwd_static_init.restype = c_int
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
 _lib.pgan_events_created.argtypes = []

@@ -36,11 +36,11 @@ def _run(tr, rs, rp, t, z, sl, dev):
     """One critic step's gradients (fakes from this rank's z rows), then one generator step's; both reduced."""
     e = tr.eng
     e.critic_grads(rs[sl].to(dev), rp[sl].to(dev), z[sl].to(dev), t[sl].to(dev) if e.loss == "gp" else None)
-    tr._allreduce(e.D.gflat)
-    out = {"d": e.D.gflat.clone().cpu(), "closs": e.closs.clone().cpu()}
+    tr._allreduce(e.D.gflat)        # leaves the sum over the ranks; Adam reads it times Engine.grad_scale = 1 / ranks
+    out = {"d": (e.D.gflat * e.grad_scale).cpu(), "closs": e.closs.clone().cpu()}
     e.generator_grads(z[sl].flip(0).contiguous().to(dev))
     tr._allreduce(e.G.gflat)
-    out.update(g=e.G.gflat.clone().cpu(), gloss=e.gloss.clone().cpu().reshape(-1),
+    out.update(g=(e.G.gflat * e.grad_scale).cpu(), gloss=e.gloss.clone().cpu().reshape(-1),
                buf={k: v.clone().cpu() for k, v in e.Gbuf.p.items()})
     return out
 
@@ -167,3 +167,82 @@ def test_trainer_iteration_over_rccl_on_one_rank(tmp_path):
         assert float((a[k] - b[k]).norm() / a[k].norm()) < 1e-3, k
     for x, y in zip(a["losses"], b["losses"]):
         assert abs(x - y) <= 1e-2 * max(1.0, abs(x))
+
+
+def _split_trainer(FusedTrainer, ops, dev, loss, batch, rank, world, pg):
+    tr = FusedTrainer(ops, batch, dev, loss=loss, critic_iter=2, seed=99, process_group=pg, rank=rank, world=world)
+    _load(tr)
+    rs, rp = orc.synthetic_alignments(24, 70)
+    tr.set_pool(rs, rp)
+    tr.enable_augment(label_noise=0.05, mono_switch=(0, 10))
+    tr.shuffle_pool(rows=True)
+    return tr
+
+
+def _split_worker(rank, world, port, loss, steps, out_dir, backend):
+    for p in (os.path.join(ROOT, "pg-alignments-gan_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _split_trainer(FusedTrainer, HipOps(dev), dev, loss, B // world, rank, world, dist.group.WORLD)
+    assert tr.global_stream and tr.sync_bn
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    e = tr.eng
+    torch.save({"g": e.G.flat.cpu(), "d": e.D.flat.cpu(), "Zw": e.Zw.cpu(), "t": e.tbuf.cpu(), "pool": tr.pool_s.cpu(),
+                "cursor": tr.cursor.cpu(), "rng": torch.stack([tr.rng_z, tr.rng_t, tr.rng_aug, tr.rng_mono]).cpu(),
+                "buf": {k: v.cpu() for k, v in e.Gbuf.p.items()}}, os.path.join(out_dir, f"split{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_two_ranks_split_one_run_sample_for_sample(tmp_path, loss, backend):
+    """FusedTrainer.step() on two ranks against one process at the whole batch, through the HIP kernels: the ranks share
+    pool order, cursor and generator streams and take their rows of every batch and draw (z, t, label-smoothing noise,
+    monomorphic-site draws) -- bit-identical inputs -- with BatchNorm statistics over the global batch; after three
+    iterations the weights agree to 1e-5 of their norm and a small fraction of the distance travelled (the reductions add
+    in another order).  The one process takes its BatchNorm statistics through the same sums / apply launches as the
+    ranks (a no-op reduction), so both sides round them alike."""
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL between two ranks needs two GPUs")
+    steps = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_split_worker, args=(2, port, loss, steps, str(tmp_path), backend), nprocs=2, join=True)
+    a, b = (torch.load(tmp_path / f"split{r}.pt", weights_only=True) for r in (0, 1))
+    assert torch.equal(a["g"], b["g"]) and torch.equal(a["d"], b["d"])
+    dev = torch.device("cuda", 0)
+    one = _split_trainer(FusedTrainer, HipOps(dev), dev, loss, B, 0, 1, None)
+    one.eng.bn_sync = lambda part: None
+    start = {"g": one.eng.G.flat.cpu(), "d": one.eng.D.flat.cpu()}
+    for _ in range(steps):
+        one.step()
+    torch.cuda.synchronize()
+    e, h = one.eng, B // 2
+    rows = lambda t, per: torch.cat([x.reshape(-1, h, per) for x in t], dim=1)
+    assert torch.equal(rows((a["Zw"], b["Zw"]), 128), e.Zw.cpu().reshape(-1, B, 128))
+    if loss == "gp":
+        assert torch.equal(rows((a["t"], b["t"]), 1), e.tbuf.cpu().reshape(1, B, 1))
+    want_rng = torch.stack([one.rng_z, one.rng_t, one.rng_aug, one.rng_mono]).cpu()
+    for r in (a, b):
+        assert torch.equal(r["pool"], one.pool_s.cpu()) and torch.equal(r["cursor"], one.cursor.cpu())
+        assert torch.equal(r["rng"], want_rng)
+    for key, ref in (("g", e.G.flat.cpu()), ("d", e.D.flat.cpu())):
+        err = float((a[key] - ref).norm() / ref.norm())
+        moved = float((ref - start[key]).norm() / ref.norm())
+        assert moved > 1e-3 and err <= 1e-5 and err <= 5e-3 * moved, (key, err, moved)
+    for k, v in e.Gbuf.p.items():
+        assert torch.allclose(a["buf"][k], v.cpu(), rtol=1e-4, atol=1e-5), k

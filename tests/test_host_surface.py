@@ -158,3 +158,29 @@ def test_parse_args_flags(tmp_path):
     assert a.loss == "div" and a.use_buffer and a.permute and a.normalize and a.gen == "tanNorm"
     assert a.batch_size == "32" and a.critic_iter == "5" and a.gp_lambda == "10" and a.gen_lr == "0.00005"
     assert list(od.iterdir()) == []            # an existing output directory is emptied, like the reference
+
+
+def test_every_enqueue_entry_point_can_be_taped():
+    """The native launch tape's registry (csrc/runtime.hip) knows every entry point that enqueues work, with the number
+    of arguments the binding passes; host-side entry points cannot be noted."""
+    import pgan_hip
+    for name, kinds in pgan_hip._SIGS.items():
+        if name in pgan_hip._Lib._HOST:
+            assert pgan_hip._lib.pgan_tape_arg_count(name.encode()) == -1, name
+        else:
+            assert pgan_hip._lib.pgan_tape_arg_count(name.encode()) == len(kinds), name
+
+
+def test_philox_words_known_answer():
+    """The numpy restatement of the device generator (tests/torch_ops.py) reproduces the Random123 known answer of
+    Philox4x32-10 (counter 0, key 0); the GPU tests hold the kernels to it word for word."""
+    import torch_ops as T
+    w = T.philox_words([0, 0, 0, 0], 0, 1)[0]
+    assert [int(x) for x in w] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+
+
+def test_library_states_its_build():
+    import pgan_hip
+    lib = ctypes.CDLL(pgan_hip.LIB_PATH)
+    lib.pgan_build_info.restype = ctypes.c_char_p
+    assert b"packed-fp32-ops=off" in lib.pgan_build_info()
