@@ -338,7 +338,9 @@ def main():
 
     from pgan_engine import disc_param_shapes, gen_param_shapes
     data = cfg.get("data", 64)
-    ps, pp = synthetic_pool(4096 if data == 64 else 2048, 20260 + 1 + rank, size=data)
+    # one pool for all ranks: the ranks of a data-parallel run split one run (same pool order, same generator streams;
+    # rank r takes its rows of every global batch and draw), so N GPUs train on the samples one GPU at N x batch would
+    ps, pp = synthetic_pool(4096 if data == 64 else 2048, 20260 + 1, size=data)
     flop_pa = flop_per_alignment(data, args.critic_iter)
 
     def make_trainer(backend):
@@ -483,21 +485,30 @@ def main():
             # HBM traffic of the family's largest launch shape from the committed PMC passes (bytes per launch):
             # rocprofv3 --pmc runs of tools/onekernel.py, separate passes for FETCH_SIZE and WRITE_SIZE; the file names
             # the commit its kernels were built from
-            traffic, traffic_of, traffic_at = None, None, None
+            # traffic: FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane loads, which carry
+            # these kernels' reads, at 64 bytes), WRITE_SIZE is exact; both include re-reads served by the on-die cache
+            traffic, traffic_of, traffic_at, traffic_raw, traffic_ratio = None, None, None, None, None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 traffic_at = pm.get("measured_at")
                 have = [k for k in conv if k[0] == dom and cname(k) in pm]
                 if have:       # the measured shape with the largest time share
                     big = max(have, key=lambda k: conv[k]["total_ms"])
-                    traffic = (pm[cname(big)]["FETCH_SIZE_KB"] + pm[cname(big)]["WRITE_SIZE_KB"]) * 1024
+                    row = pm[cname(big)]
+                    traffic_raw = (row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024
+                    traffic = (2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024
+                    traffic_ratio = round(traffic / ((row["algorithmic_in_KB"] + row["algorithmic_out_KB"]) * 1024), 3)
                     traffic_of = cname(big)
-            except (OSError, ValueError):
+            except (OSError, ValueError, KeyError):
                 pass
             kname = dom + "_x3_kernel" if pipe[dom] != "fp32" else dom + "_kernel"
             roofline = dict(bound="mfma", kernel=f"{kname} ({pipe[dom]} matrix pipe, implicit GEMM)",
                             achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             traffic=traffic, traffic_shape=traffic_of, traffic_measured_at=traffic_at,
+                            traffic_over_algorithmic=traffic_ratio, traffic_raw_counters=traffic_raw,
+                            traffic_note="bytes per launch of traffic_shape: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, "
+                                         "separate passes; FETCH_SIZE doubled for 16-byte-per-lane loads on gfx950); "
+                                         "algorithmic = operands read once (fp16 weight planes, fp32 activations) + output",
                             algorithmic_tflops=round(alg, 3),
                             algorithmic_frac_of_fp32_mfma_peak=round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                             note=(f"achieved / peak / frac price the {pipe[dom]} MFMA work actually executed ({mult:g} partial "

@@ -283,6 +283,9 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if "--one-step-only" in sys.argv:      # adds the one-step fixture without rewriting the others
+        one_step_fixture(ref)
+        return
     forward_fixture(ref, 4, 100)
     critic_fixture(ref, 4, 200, "gp")
     critic_fixture(ref, 4, 300, "div")
@@ -292,7 +295,15 @@ def main():
     train_fixture(ref, 8, 700, "gp", "sigmoid", False, iters=3)
     train_fixture(ref, 8, 800, "gp", "tanh", True, iters=2)
     train_fixture(ref, 8, 900, "div", "sigmoid", False, iters=2)
+    one_step_fixture(ref)
     print("golden fixtures written to", OUT)
+
+
+def one_step_fixture(ref):
+    """One critic step + one generator step (critic_iter 1, one iteration): both optimizers have made exactly one step, so
+    exp_avg = (1 - beta1) g and exp_avg_sq = (1 - beta2) g^2 of torch.optim.Adam pin the first gradients and the fused
+    Adam's moment arithmetic; written as train_gp_sigmoid_onestep_B8.npz."""
+    train_fixture(ref, 8, 1000, "gp", "sigmoid", False, iters=1, critic_iter=1, tag="gp_sigmoid_onestep")
 
 
 if __name__ == "__main__":

@@ -142,3 +142,27 @@ def test_training_trajectory_matches_reference(fname, loss, act):
             check_summary(g, f"G.{k}", v, rtol=5e-3)
         else:
             assert int(v) == 6 * iters
+
+
+def test_one_step_adam_state_matches_reference_optimizer():
+    """One critic step + one generator step (critic_iter 1): the oracle's Adam restatement against the state of the
+    reference's torch.optim.Adam instances (exp_avg, exp_avg_sq after exactly one step of each optimizer) and the
+    updated weights (train_gp_sigmoid_onestep_B8.npz, written from the reference's modules)."""
+    g = load_golden("train_gp_sigmoid_onestep_B8.npz")
+    B, seed, lam, iters, critic_iter, normalize = [int(v) for v in g["meta"]]
+    assert (iters, critic_iter, normalize) == (1, 1, 0)
+    gp_ = orc.make_params(orc.gen_param_shapes(), seed)
+    dp = orc.make_params(orc.disc_param_shapes(), seed + 1)
+    gbuf = orc.make_gen_buffers()
+    d_opt, g_opt = orc.AdamState(dp), orc.AdamState(gp_)
+    rs, rp = orc.synthetic_alignments(B, seed + 3)
+    w, gl = orc.train_iteration(dp, gp_, gbuf, d_opt, g_opt, [(rs, rp)], [z_draw(seed + 1000, B), z_draw(seed + 1001, B)],
+                                [t_draw(seed + 5000, B)], "gp", lam, "sigmoid", False)
+    ref = g["traj"][0]
+    assert abs(w - ref[0]) <= 1e-5 * max(1.0, abs(ref[0])) and abs(gl - ref[1]) <= 1e-5 * max(1.0, abs(ref[1]))
+    lr = 5e-5
+    for name, opt, params in (("D", d_opt, dp), ("G", g_opt, gp_)):
+        for k in params:
+            check_summary(g, f"{name}.exp_avg.{k}", opt.m[k], rtol=1e-4)
+            check_summary(g, f"{name}.exp_avg_sq.{k}", opt.v[k], rtol=2e-4, atol=1e-16)
+            check_summary(g, f"{name}.{k}", params[k], rtol=1e-5, atol=2 * lr)
