@@ -71,7 +71,11 @@ constexpr float LO_SCALE = 2048.f;      // 2^11: the second fp16 plane is stored
 // (x, y) -> NPL packed 16-bit pairs; low half belongs to x.
 __device__ __forceinline__ void split3(float x, float y, uint32_t (&p)[NPL]) {
     f32x2 v = {x, y};
-#ifdef PGAN_SPLIT_F16
+#if defined(PGAN_SPLIT_F16) && defined(PGAN_ABLATE_SPLIT)
+    // timing experiment only (results are meaningless): no split arithmetic, as if the operand arrived as prepared planes
+    p[0] = __builtin_bit_cast(uint32_t, x) & 0x3BFF3BFFu;
+    p[1] = __builtin_bit_cast(uint32_t, y) & 0x3BFF3BFFu;
+#elif defined(PGAN_SPLIT_F16)
     const f16x2 h1 = __builtin_convertvector(v, f16x2);
     p[0] = __builtin_bit_cast(uint32_t, h1);
     const f32x2 r = (v - __builtin_convertvector(h1, f32x2)) * LO_SCALE;

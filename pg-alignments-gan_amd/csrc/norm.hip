@@ -11,6 +11,7 @@
 #include "pgan_common.h"
 
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -20,14 +21,31 @@ namespace {
 // write hold different channels, so no atomics are needed and the sums do not depend on the waves' timing; the caller
 // adds the rows in a fixed order (channel_total) after a barrier.
 constexpr int CW = 4;
-template <int NV>
-__device__ __forceinline__ void channel_accumulate(float (&v)[NV], float* const (&sh)[NV], int c, int GL) {
+// Sum of v over the GL consecutive lanes (4 ... 64) that share a channel, in every one of them: lane distances 1-8
+// are data-parallel-primitive adds at vector-ALU rate (the quad steps leave all lanes of a quad equal, so the 8- and
+// 16-lane mirrors pair every lane with its partner's sum), only 16 and 32 go through the LDS crossbar.  These per-channel
+// reductions run once per loop iteration of the backward kernels' sums passes; done as six dependent crossbar shuffles
+// each, they -- not the bytes streamed -- set those kernels' time.
+template <int GL>
+__device__ __forceinline__ float group_sum(float x) {
+    static_assert(GL == 4 || GL == 8 || GL == 16 || GL == 32 || GL == 64, "lanes per channel");
+    x += dpp_move<0xB1>(x);
+    x += dpp_move<0x4E>(x);
+    if constexpr (GL >= 8) x += dpp_move<0x141>(x);
+    if constexpr (GL >= 16) x += dpp_move<0x140>(x);
+    if constexpr (GL >= 32) x += __shfl_xor(x, 16, 64);
+    if constexpr (GL >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+template <int GL, int NV>
+__device__ __forceinline__ void channel_accumulate(float (&v)[NV], float* const (&sh)[NV], int c) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        float x = v[i];
-        for (int o = 1; o < GL; o <<= 1) x += __shfl_xor(x, o, 64);
-        if ((lane & (GL - 1)) == 0) sh[i][wave * 64 + c] += x;
+    for (int i = 0; i < NV; ++i) x[i] = group_sum<GL>(v[i]);        // independent chains: their latencies overlap
+    if ((lane & (GL - 1)) == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sh[i][wave * 64 + c] += x[i];
     }
 }
 __device__ __forceinline__ float channel_total(const float* sh, int c) {
@@ -142,7 +160,7 @@ __device__ __forceinline__ float mask_of(float hv, float g, float xh, float b) {
 
 // first-order backward: d = J (gamma m u); per-sample stats (mean w, mean w xh); per-sample
 // per-channel partial sums of the gamma / beta gradients.
-template <bool MA>
+template <bool MA, int GL>
 __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, const float* __restrict__ h,
                                                   const float* __restrict__ a, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
     __shared__ double sh[2 * ST / 64];
     __shared__ float cg[CW * 64], cb[CW * 64];
     const Slice sl(M, C);
-    const int GL = min(64, HW / 4), cps = C / SL;
+    const int cps = C / SL;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
     const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(ST) void gn_bwd_sums(const float* __restrict__ u, c
             pe[1] += ee;
         }
         float* const dst[2] = {cg, cb};
-        channel_accumulate<2>(pe, dst, cl, GL);
+        channel_accumulate<GL, 2>(pe, dst, cl);
     }
     double red[2] = {sw, swx};
     put_partials<2>(red, sh, ws, sl);   // its barriers also order the per-wave channel rows before the reads below
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(ST) void gn_jvp_apply(const float* __restrict__ t, 
 //   w = gamma m u, q = gamma m hbar, Q = q - r (c w + mwx t)
 //   p = r [ Q - mean Q - xh (mean(Q xh) + mean(w xd)) ],  xd = r (t - tb - xh c)
 // plus per-channel partials  pg = sum m u xd + m hbar xh,  pb = sum m hbar.   hbar may be null (= 0).
-template <bool MA>
+template <bool MA, int GL>
 __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hbar, const float* __restrict__ u,
                                                    const float* __restrict__ t, const float* __restrict__ h,
                                                    const float* __restrict__ a, const float* __restrict__ stats,
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
     __shared__ double sh[3 * ST / 64];
     __shared__ float cg[CW * 64], cb[CW * 64];
     const Slice sl(M, C);
-    const int GL = min(64, HW / 4), cps = C / SL;
+    const int cps = C / SL;
     const f32x4* hb4 = hbar ? reinterpret_cast<const f32x4*>(hbar + sl.base) : nullptr;
     const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
     const f32x4* t4 = reinterpret_cast<const f32x4*>(t + sl.base);
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(ST) void gn_bwd2_sums(const float* __restrict__ hba
             pe[1] += m * bv[e];
         }
         float* const dst[2] = {cg, cb};
-        channel_accumulate<2>(pe, dst, cl, GL);
+        channel_accumulate<GL, 2>(pe, dst, cl);
     }
     double red[3] = {sq, sqx, swt};
     put_partials<3>(red, sh, ws, sl);
@@ -742,11 +760,25 @@ int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* sta
                 float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C || (!beta && !h)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
+    // lanes per channel in the sums pass: a thread takes four consecutive elements, a channel is HW of them
+    auto sums = [&](auto ma, auto gl) {
+        gn_bwd_sums<decltype(ma)::value, decltype(gl)::value><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, pg, pb, w,
+                                                                                     C * HW, HW, C, pld);
+    };
+    auto by_hw = [&](auto ma) {
+        switch (HW) {
+            case 16: sums(ma, std::integral_constant<int, 4>{}); break;
+            case 32: sums(ma, std::integral_constant<int, 8>{}); break;
+            case 64: sums(ma, std::integral_constant<int, 16>{}); break;
+            case 128: sums(ma, std::integral_constant<int, 32>{}); break;
+            default: sums(ma, std::integral_constant<int, 64>{});
+        }
+    };
     if (beta) {
-        gn_bwd_sums<true><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        by_hw(std::true_type{});
         gn_bwd_apply<true><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, d, stats_b, w, C * HW, HW, C, amax);
     } else {
-        gn_bwd_sums<false><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        by_hw(std::false_type{});
         gn_bwd_apply<false><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, d, stats_b, w, C * HW, HW, C, amax);
     }
     return pgan_launch_status();
@@ -767,11 +799,24 @@ int pgan_gn_bwd2(const float* hbar, const float* u, const float* t, const float*
                  float* pb, int pld, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
     if (!gn_shape_ok(N, C, HW, ws, ws_bytes) || pld < C || (!beta && !h)) return PGAN_EINVAL;
     double* w = static_cast<double*>(ws);
+    auto sums = [&](auto ma, auto gl) {
+        gn_bwd2_sums<decltype(ma)::value, decltype(gl)::value><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma,
+                                                                                      beta, pg, pb, w, C * HW, HW, C, pld);
+    };
+    auto by_hw = [&](auto ma) {
+        switch (HW) {
+            case 16: sums(ma, std::integral_constant<int, 4>{}); break;
+            case 32: sums(ma, std::integral_constant<int, 8>{}); break;
+            case 64: sums(ma, std::integral_constant<int, 16>{}); break;
+            case 128: sums(ma, std::integral_constant<int, 32>{}); break;
+            default: sums(ma, std::integral_constant<int, 64>{});
+        }
+    };
     if (beta) {
-        gn_bwd2_sums<true><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        by_hw(std::true_type{});
         gn_bwd2_apply<true><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, beta, p, w, C * HW, HW, C, amax);
     } else {
-        gn_bwd2_sums<false><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_t, gamma, beta, pg, pb, w, C * HW, HW, C, pld);
+        by_hw(std::false_type{});
         gn_bwd2_apply<false><<<N * SL, ST, 0, st>>>(hbar, u, t, h, a, stats, stats_b, stats_t, gamma, beta, p, w, C * HW, HW, C, amax);
     }
     return pgan_launch_status();

@@ -268,10 +268,11 @@ class Engine:
         # the ranks of a data-parallel run
         self.grad_scale = 1.0
         self.two_chains = os.environ.get("PGAN_TWO_CHAINS", "1") != "0"
-        # weight gradients of the Wasserstein samples right after their backward, the penalised samples' share added
-        # later (two half-size passes per stage instead of one): the first half leaves the weight-gradient stream early,
-        # beside the penalty chain (7.26 -> 7.10 ms per iteration; PGAN_SPLIT_WGRAD=0: one pass over all slots)
-        self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "1") != "0"
+        # PGAN_SPLIT_WGRAD=1: weight gradients of the Wasserstein samples right after their backward, the penalised samples'
+        # share added later (two half-size passes per stage instead of one).  It won 0.16 ms per iteration when the
+        # weight-gradient kernel was slower; with the current kernels one pass over all slots is 0.03-0.07 ms faster
+        # (same-box A/B, 6.99 -> 6.91 / 6.92 ms), so one pass is the default.
+        self.split_wgrad = os.environ.get("PGAN_SPLIT_WGRAD", "0") != "0"
         # loss / norm-gradient / head-gradient launches of a critic step beside its last weight-gradient passes
         # (PGAN_TAIL_BESIDE_WGRAD=0: after them, for comparison)
         self.tail_beside_wgrad = os.environ.get("PGAN_TAIL_BESIDE_WGRAD", "1") != "0"

@@ -635,6 +635,14 @@ class HipOps:
     def release_weights(self) -> None:
         self._hold = False
 
+    # timing experiment (PGAN_DUMMY_LAUNCHES=k): k empty launches after every GroupNorm op, on its stream -- what one more
+    # dependent launch on a chain costs
+    _dummy = int(os.environ.get("PGAN_DUMMY_LAUNCHES", "0"))
+
+    def _dummies(self):
+        for _ in range(self._dummy):
+            _check(_lib.pgan_affine(self.ws_small.data_ptr(), self.ws_small.data_ptr() + 1024, 4, 1.0, 0.0, _stream()), "dummy")
+
     def gn_fwd(self, a, gamma, beta, h, stats, amax=None, presummed=False):
         """amax (every GroupNorm op): optional [N, GN_AMAX_SLOTS] output, the largest magnitude of each of the eight
         slices of every sample of the op's main output -- what conv_* take as `bound`.
@@ -644,9 +652,11 @@ class HipOps:
             _check(_lib.pgan_gn_fwd_presummed(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C,
                                               _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()),
                    "pgan_gn_fwd_presummed")
+            self._dummies()
             return
         _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_fwd")
+        self._dummies()
 
     def gn_fwd_static(self, a, gamma, beta, h, stats):
         """gn_fwd with the partial sums in the library's own fixed array (nothing allocated, no workspace)."""
@@ -660,17 +670,20 @@ class HipOps:
         _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(d), _ptr(stats_b),
                                 _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd")
+        self._dummies()
 
     def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(hd), _ptr(stats_t),
                                 *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_jvp")
+        self._dummies()
 
     def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
                                  _ptr(stats_t), _ptr(gamma), _ptr(beta), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
                                  *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd2")
+        self._dummies()
 
     # ---------------- BatchNorm ----------------
     def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1, amax=None):
