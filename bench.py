@@ -288,8 +288,10 @@ def main():
     ap.add_argument("--use-buffer", type=int, default=None, help="replay buffer of this many batches (0: none)")
     ap.add_argument("--permute", action="store_true", default=None, help="row-permuted real alignments")
     ap.add_argument("--critic-iter", type=int, default=5)
-    ap.add_argument("--route", default="auto", choices=["auto", "eager", "tape", "graph"],
-                    help="how an iteration is enqueued (auto: the fastest of the available ones, measured)")
+    ap.add_argument("--route", default="tape", choices=["auto", "eager", "tape", "graph"],
+                    help="how an iteration is enqueued: the launch tape replayed by the library (default; the fastest route in "
+                         "every same-box comparison, and the one that also carries collectives), eager Python calls, a "
+                         "hipGraph replay (one GPU only), or auto = time all available ones first and take the fastest")
     ap.add_argument("--no-graph", action="store_true", help="same as --route eager")
     ap.add_argument("--separate-generator-forwards", action="store_true",
                     help="one generator forward per critic step instead of the iteration's forwards batched")
@@ -382,7 +384,7 @@ def main():
     # Three routes enqueue the same kernels on the same streams: eager launches from Python (about 8 ms of host time per
     # iteration), a launch tape (the same calls replayed from a flat list, about a third of that) and a hipGraph replay
     # (no host work, but the runtime's own placement of the graph's branches; one GPU only -- no capture around RCCL).
-    # Whichever is fastest here is used: decided on 10 untimed iterations of each.
+    # The tape is the default; --route auto times 10 untimed iterations of each and takes the fastest.
     def rate(fn, n=10):
         fn()
         torch.cuda.synchronize()
@@ -417,6 +419,9 @@ def main():
     best = min(times, key=times.get)
     step, use_graph = routes[best], best == "graph"
     route = best + " (calibration, ms per iteration: " + ", ".join(f"{k} {v * 1e3:.2f}" for k, v in sorted(times.items())) + ")"
+    ct = getattr(tr, "tape", None)
+    if best == "tape" and hasattr(ct, "native_calls"):
+        route += f"; {ct.native_calls} library calls replayed from C, {ct.python_steps} Python steps between them"
     for _ in range(args.warmup):
         step()
 

@@ -266,6 +266,12 @@ __global__ __launch_bounds__(256) void prep_multi_kernel(PrepSet ps) {
 // range, each with its own LDS buffers; group 1 hands its sums to group 0 through LDS at the end (a fixed order:
 // deterministic).  gridDim.y = 2 splits the range once more over two blocks that add into a zeroed Y -- two
 // addends, so the result does not depend on which block comes first.
+// PGAN_ABL_DOWN (debugging builds only, results are wrong): leave out parts of the DOWN kernel's main loop -- 1 the MFMAs
+// (operands are folded into the sums with one integer add so that their loads stay), 2 the weight-fragment loads, 4 the
+// staging stores into LDS, 16 the LDS reads.  Used to find which part of this kernel disturbs a neighbour.
+#ifndef PGAN_ABL_DOWN
+#define PGAN_ABL_DOWN 0
+#endif
 template <int HS, int BM, int BN, int CLC, int KG>
 __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void conv_down_x3_kernel(const float* __restrict__ X, const uint16_t* __restrict__ WP,
                                                            float* __restrict__ Y, int N, int Cs, int Cl,
@@ -393,16 +399,22 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     auto chunk_cl = [&](int kc) { return (kc0 + (kc < nk ? kc : nk - 1)) * CLC; };
 
     auto chunk = [&](auto setc, int clbase, const uint32_t* cur, uint32_t* nxt) {
-        ldops(cur, IC<0>{});
+        if constexpr (!(PGAN_ABL_DOWN & 16)) ldops(cur, IC<0>{});
         static_for<S>([&](auto sc) {
             constexpr int s = decltype(sc)::value, c = s / (TM * TN), t = s % (TM * TN), tm = t / TN, tn = t % TN;
             if constexpr (t == 0) {
-                if constexpr (c + 1 < CLC) ldops(cur, IC<c + 1>{});
-                aload(IC<(c + 1) & 1>{}, min(clbase + c + 1, cl_last));
+                if constexpr (c + 1 < CLC && !(PGAN_ABL_DOWN & 16)) ldops(cur, IC<c + 1>{});
+                if constexpr (!(PGAN_ABL_DOWN & 2)) aload(IC<(c + 1) & 1>{}, min(clbase + c + 1, cl_last));
             }
-            mfma_x3(a[c & 1][tm], bo[c & 1][tn], acc[tm][tn], acl[tm][tn]);
+            if constexpr (PGAN_ABL_DOWN & 1) {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i)
+                    acc[tm][tn][i] += __builtin_bit_cast(float, (a[c & 1][tm][i][0] + bo[c & 1][tn][i][0]) & 0x3fffffffu);
+            } else {
+                mfma_x3(a[c & 1][tm], bo[c & 1][tn], acc[tm][tn], acl[tm][tn]);
+            }
             constexpr int lo = s * NST / S, hi = (s + 1) * NST / S;
-            static_for<hi - lo>([&](auto ic) { stage(setc, IC<lo + decltype(ic)::value>{}, nxt); });
+            if constexpr (!(PGAN_ABL_DOWN & 4)) static_for<hi - lo>([&](auto ic) { stage(setc, IC<lo + decltype(ic)::value>{}, nxt); });
         });
     };
 

@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgan_hip.so")
+# PGAN_HIP_LIBRARY names another build of the same library (debugging: tools/dbg/racefind5.py loads a packed-fp32 build)
+LIB_PATH = os.environ.get("PGAN_HIP_LIBRARY") or os.path.join(_HERE, "libpgan_hip.so")
 
 
 class PganError(RuntimeError):

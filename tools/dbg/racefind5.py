@@ -63,7 +63,6 @@ for rep in range(int(os.environ.get("REPS", "200"))):
             d = torch.nan_to_num(tmp, nan=-7.0) != torch.nan_to_num(got, nan=-7.0)
             slots = torch.nonzero(d.reshape(d.shape[0], -1).any(1)).flatten().tolist()
             nz = torch.nonzero(d)
-            nz = torch.nonzero(d)
             truth = torch.nn.functional.conv2d(eng.X0[lo:hi].double(), eng.dconv_w(1).double(), stride=2, padding=1)
             e_got = float((got.double() - truth).abs().max())
             e_tmp = float((tmp.double() - truth).abs().max())
@@ -76,8 +75,15 @@ for rep in range(int(os.environ.get("REPS", "200"))):
             hist_c = torch.bincount(nz[:, 1], minlength=64).tolist()
             msgs.append(f"max error vs fp64: in-step {e_got:.2e}, recomputed {e_tmp:.2e}; by h {hist_h}; by w {hist_w}; by c {hist_c}")
             msgs.extend(ex)
-            msgs.append(f"stage-1 activations of the {name} slots differ from conv_down(final input): {int(d.sum())} elements, "
-                        f"{int(torch.isnan(got).sum())} NaN, slots {slots}, index range {nz.min(0).values.tolist()} .. {nz.max(0).values.tolist()}")
+            # what the wrong values are made of: the fp64 contribution of every kernel row kh to the element, for its own
+            # channel and for the channels next to it (a stale weight row would show as one row taken from a neighbour)
+            wd = eng.dconv_w(1).double()
+            xin = torch.nn.functional.pad(eng.X0[lo:hi].double(), (1, 1, 1, 1))
+            for n_, c_, h_, w_ in nz[:: max(1, nz.shape[0] // 6)].tolist():
+                terms = [[float(xin[n_, 0, 2 * h_ + kh, 2 * w_ + kw] * wd[c_, 0, kh, kw]) for kw in range(4)] for kh in range(4)]
+                delta = float(got[n_, c_, h_, w_]) - float(truth[n_, c_, h_, w_])
+                msgs.append(f"({n_},{c_},{h_},{w_}) got - truth {delta:+.6f}; the 16 products x[kh][kw] * w[kh][kw]: "
+                            + " | ".join(" ".join("%+.5f" % v for v in row) for row in terms))
     nan_any = {n: int(torch.isnan(t).sum()) for n, t in (("X0", eng.X0), ("G0", eng.G0), ("Dg", eng.D.gflat), ("closs", eng.closs))}
     if any(nan_any.values()):
         msgs.append(f"NaN left: {nan_any}")
