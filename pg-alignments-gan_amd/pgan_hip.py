@@ -498,12 +498,39 @@ class HipOps:
         return ent[0].data_ptr()
 
     # ---------------- conv family ----------------
+    # Debugging mode (PGAN_CHECK_BOUNDS=1, eager launches only): before every split convolution that is given magnitude
+    # bounds, wait for the stream and compare them with the operand's true magnitudes -- a bound below the truth could
+    # overflow fp16 inside the kernel without any error.  bounds_checked counts the comparisons made.
+    check_bounds = os.environ.get("PGAN_CHECK_BOUNDS", "0") == "1"
+    bounds_checked = 0
+
+    def _verify_bound(self, what: str, operand: torch.Tensor, n: int, bound: Optional[torch.Tensor]) -> None:
+        if bound is None or not self.check_bounds:
+            return
+        if self.capturing or pgan_tape.tape is not None:
+            raise PganError("PGAN_CHECK_BOUNDS needs eager launches (it synchronises and reads the operands)")
+        torch.cuda.current_stream().synchronize()
+        x = operand[:n]
+        if bound.dim() == 2:      # k entries per sample, each bounding one slice: their maximum bounds the sample
+            true = x.abs().reshape(n, -1).amax(dim=1)
+            have = bound[:n].amax(dim=1)
+        else:                     # every entry bounds the whole operand; the kernels use the largest
+            true = x.abs().amax().reshape(1)
+            have = bound.amax().reshape(1)
+        ok = have >= true         # False for NaN on either side
+        HipOps.bounds_checked += 1
+        if not bool(ok.all()):
+            i = int((~ok).nonzero()[0])
+            raise PganError(f"{what}: magnitude bound {float(have[i]):.6g} is below the operand's {float(true[i]):.6g} "
+                            f"(row {i} of {tuple(bound.shape)}; operand {tuple(x.shape)})")
+
     def conv_down(self, x, w, y, bound=None):
         """bound: magnitude bounds of x from its producer (see _bound); without them the fp16-split kernel scans x."""
         N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
         Cs, hs = w.shape[0], HL // 2
         assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
         if self.split and Cl > 1:
+            self._verify_bound("conv_down", x, N, bound)
             fn = _lib.pgan_conv_down_h2 if self.precision == "h2" else _lib.pgan_conv_down_x3
             _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
                    "pgan_conv_down (split)")
@@ -533,6 +560,7 @@ class HipOps:
         Cl = w.shape[1]
         assert tuple(x.shape) == (N, Cl, 2 * hs, 2 * hs) and w.shape[0] == Cs
         if self.split and Cl > 1 and act == 0:
+            self._verify_bound("conv_up", y, N, bound)
             fn = _lib.pgan_conv_up_h2 if self.precision == "h2" else _lib.pgan_conv_up_x3
             _check(fn(_ptr(y), self._weight_planes(w), _ptr(x), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
                    "pgan_conv_up (split)")
@@ -548,6 +576,8 @@ class HipOps:
             n_keep = N
         assert tuple(dw.shape[:2]) == (Cs, Cl) and x.shape[0] >= N and x.shape[2] == 2 * hs
         if self.split and self.wgrad_x3 and Cl > 1:
+            self._verify_bound("conv_wgrad (S operand)", ya, N, bound_s)
+            self._verify_bound("conv_wgrad (L operand)", x, N, bound_l)
             h2 = self.precision == "h2"
             need = (_lib.pgan_conv_wgrad_h2_workspace_floats if h2 else _lib.pgan_conv_wgrad_x3_workspace_floats)(N, Cs, Cl, hs)
             if need < 0 or need > self.ws.numel():
@@ -636,14 +666,6 @@ class HipOps:
     def release_weights(self) -> None:
         self._hold = False
 
-    # timing experiment (PGAN_DUMMY_LAUNCHES=k): k empty launches after every GroupNorm op, on its stream -- what one more
-    # dependent launch on a chain costs
-    _dummy = int(os.environ.get("PGAN_DUMMY_LAUNCHES", "0"))
-
-    def _dummies(self):
-        for _ in range(self._dummy):
-            _check(_lib.pgan_affine(self.ws_small.data_ptr(), self.ws_small.data_ptr() + 1024, 4, 1.0, 0.0, _stream()), "dummy")
-
     def gn_fwd(self, a, gamma, beta, h, stats, amax=None, presummed=False):
         """amax (every GroupNorm op): optional [N, GN_AMAX_SLOTS] output, the largest magnitude of each of the eight
         slices of every sample of the op's main output -- what conv_* take as `bound`.
@@ -653,11 +675,9 @@ class HipOps:
             _check(_lib.pgan_gn_fwd_presummed(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C,
                                               _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()),
                    "pgan_gn_fwd_presummed")
-            self._dummies()
             return
         _check(_lib.pgan_gn_fwd(_ptr(a), _ptr(gamma), _ptr(beta), _ptr(h), _ptr(stats), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_fwd")
-        self._dummies()
 
     def gn_fwd_static(self, a, gamma, beta, h, stats):
         """gn_fwd with the partial sums in the library's own fixed array (nothing allocated, no workspace)."""
@@ -671,20 +691,17 @@ class HipOps:
         _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(d), _ptr(stats_b),
                                 _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd")
-        self._dummies()
 
     def gn_jvp(self, t, h, a, stats, gamma, hd, stats_t, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_jvp(_ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(hd), _ptr(stats_t),
                                 *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_jvp")
-        self._dummies()
 
     def gn_bwd2(self, hbar, u, t, h, a, stats, stats_b, stats_t, gamma, p, pg, pb, amax=None, beta=None):
         N, C = a.shape[0], a.shape[1]
         _check(_lib.pgan_gn_bwd2(_ptr(hbar), _ptr(u), _ptr(t), _ptr(h), _ptr(a), _ptr(stats), _ptr(stats_b),
                                  _ptr(stats_t), _ptr(gamma), _ptr(beta), _ptr(p), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0),
                                  *self._gnws(), N, C, _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd2")
-        self._dummies()
 
     # ---------------- BatchNorm ----------------
     def bn_fwd(self, a, gamma, beta, rmean, rvar, h, stats, momentum=0.1, groups=1, amax=None):

@@ -635,3 +635,47 @@ def test_scaled_128_trainer_routes_agree(hip):
         for k in ("d", "g"):
             assert float((out["eager"][k] - out[route][k]).abs().max()) <= 2 * lr * 2 * n_it, (route, k)
             assert rel_err(out[route][k], out["eager"][k]) < 1e-3, (route, k)
+
+
+@pytest.mark.parametrize("loss,sync_bn", [("gp", False), ("div", False), ("gp", True)])
+def test_operand_bounds_hold_in_every_split_convolution(hip, loss, sync_bn, monkeypatch):
+    """The fp16-split convolutions trust the magnitude bounds their producers report (a bound below the truth could
+    overflow fp16 silently).  With the backend's checking mode on, every bounded convolution of a critic step and a
+    generator step -- forward, both backward passes, tangent pass, weight gradients; BatchNorm statistics in one launch
+    and as the data-parallel sums / apply pair -- compares its bounds with the operand's true magnitudes first."""
+    from pgan_hip import HipOps
+    B, seed = 8, 99
+    eng, gp_, dp = make_engine(hip, B, loss, "sigmoid", seed)
+    if sync_bn:
+        eng.bn_sync = lambda part: None          # one rank's share is the whole batch: the sums are already global
+    # weights far from their initial scale, so that the magnitudes differ by orders between stages
+    with torch.no_grad():
+        for k, v in eng.D.p.items():
+            if k.endswith("weight") and v.dim() == 4:
+                v.mul_(6.0)
+    eng.ops.invalidate_weight_planes(reset=True)
+    monkeypatch.setattr(HipOps, "check_bounds", True)
+    before = HipOps.bounds_checked
+    rs, rp = orc.synthetic_alignments(B, seed + 3)
+    eng.critic_grads(rs.to(DEV), rp.to(DEV), z_draw(seed + 2, B).to(DEV), t_draw(seed + 4, B).to(DEV))
+    eng.generator_grads(z_draw(seed + 5, B).to(DEV))
+    torch.cuda.synchronize()
+    made = HipOps.bounds_checked - before
+    print(f"{loss}, sync_bn={sync_bn}: {made} bounds compared with their operands")
+    assert made >= 40, made
+    assert torch.isfinite(eng.D.gflat).all() and torch.isfinite(eng.G.gflat).all()
+
+
+def test_bound_check_catches_a_bound_below_the_operand(hip, monkeypatch):
+    from pgan_hip import HipOps, PganError
+    monkeypatch.setattr(HipOps, "check_bounds", True)
+    x = torch.randn(4, 64, 32, 32, device=DEV)
+    w = torch.randn(128, 64, 4, 4, device=DEV) * 0.05
+    y = torch.empty(4, 128, 16, 16, device=DEV)
+    good = x.abs().reshape(4, 8, -1).amax(dim=2).contiguous()
+    hip.conv_down(x, w, y, bound=good)
+    bad = good.clone()
+    bad[2] *= 0.5
+    with pytest.raises(PganError, match="below the operand"):
+        hip.conv_down(x, w, y, bound=bad)
+    torch.cuda.synchronize()
