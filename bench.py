@@ -156,9 +156,19 @@ class RecordingOps:
         launches replayed from a hipGraph (no host work between the launches: the shortest kernels here take 3 us, a
         launch through Python 5-10); shapes whose launches cannot be captured are timed with the queue fed from Python.
         stream: an existing (idle) stream to capture on -- a new one would shift which hardware queue later streams get."""
+        import pgan_hip
         from pgan_hip import StepGraph
         out = {}
         cap = stream if stream is not None else torch.cuda.Stream()
+        # markers for a kernel trace of this run: one launch of a kernel nothing else here uses (the loader's bit packer on
+        # one alignment) right before and right after every timed region, so that tools/trace_shapes.py can cut the trace
+        # into the same regions, in the order of the `per_shape` table
+        mark_in = torch.zeros(64 * 64, device="cuda")
+        mark_out = torch.zeros(512, dtype=torch.uint8, device=mark_in.device)
+
+        def marker():
+            pgan_hip._lib.pgan_pack_sites(mark_in.data_ptr(), mark_out.data_ptr(), 1, cap.cuda_stream)
+
         if hasattr(self._ops, "reserve_stream"):
             self._ops.reserve_stream(cap.cuda_stream)
         for key, rec in self.calls.items():
@@ -181,6 +191,7 @@ class RecordingOps:
                 if graph is not None:
                     graph.launch()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                marker()
                 s.record()
                 if graph is not None:
                     graph.launch()
@@ -188,6 +199,7 @@ class RecordingOps:
                     for _ in range(reps):
                         fn(*a, **k)
                 e.record()
+                marker()
                 e.synchronize()
             ms = s.elapsed_time(e) / reps
             out[key] = dict(calls=rec["count"], ms=ms, total_ms=ms * rec["count"], flops=rec["flops"], bytes=rec["bytes"],
@@ -555,7 +567,10 @@ def main():
                    step_tflops=round(value * flop_pa / 1e12, 3), flop_per_alignment=flop_pa,
                    step_frac_of_fp32_mfma_peak=round(value * flop_pa / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
                    losses=dict(critic=losses[0], d_real=losses[1], d_fake=losses[2], penalty=losses[3], generator=losses[4]),
-                   roofline=roofline, hbm_kernels=hbm)
+                   roofline=roofline, hbm_kernels=hbm,
+                   # the launch shapes in the order they were timed (= the order of the marker pairs in a kernel trace)
+                   timed_shapes=[(cname(k) if k[0].startswith("conv_") else f"{k[0]}{list(k[1:])}") + f" {v['ms'] * 1e3:.2f}us"
+                                 for k, v in summ.items()])
         if world == 1 and x3 and not args.no_fp32_pipe and data == 64:
             # the same step with the other arithmetic choices, for reference: three bf16 planes / six products, and
             # every convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32)

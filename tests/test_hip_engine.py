@@ -662,7 +662,7 @@ def test_operand_bounds_hold_in_every_split_convolution(hip, loss, sync_bn, monk
     torch.cuda.synchronize()
     made = HipOps.bounds_checked - before
     print(f"{loss}, sync_bn={sync_bn}: {made} bounds compared with their operands")
-    assert made >= 40, made
+    assert made >= 30, made
     assert torch.isfinite(eng.D.gflat).all() and torch.isfinite(eng.G.gflat).all()
 
 
