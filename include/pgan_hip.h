@@ -155,6 +155,21 @@ int pgan_gn_fwd_static_max_samples(void);
 int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
                 float* d, float* stats_b, float* pg, float* pb, int pld /* row stride of pg, pb */, void* ws,
                 long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);
+/* One-launch forms of the GroupNorm ops (same reference ops, src/layers.py:442-466 and autograd's backward / double
+ * backward through them): a block keeps the eighth of a sample it read for the sums in registers and applies from there,
+ * so every input is read once; the eight blocks of a sample exchange their partial sums through ws1 inside the launch.
+ * ws1: pgan_gn_onepass_workspace_bytes(N) bytes of device memory, one per stream that issues these calls, passed ONCE
+ * through pgan_gn_onepass_workspace_init after allocation (every call leaves it in that state again; do not share it
+ * between streams).  Shapes: C * HW / 8192 in {1, 2, 4, 8}; others return -1 and launch nothing (use the two-launch
+ * call).  Results equal the two-launch call's bit for bit.  A block never waits unboundedly for its sample's other
+ * blocks: if it gives up (a workspace that was not initialised, or shared), the call's results are wrong and
+ * pgan_gn_onepass_workspace_error returns 1 from then on. */
+long long pgan_gn_onepass_workspace_bytes(int N);
+int pgan_gn_onepass_workspace_init(void* ws1, long long ws1_bytes, int N, hipStream_t st);
+int pgan_gn_onepass_workspace_error(const void* ws1, int N, hipStream_t st);      /* synchronises st */
+int pgan_gn_bwd_onepass(const float* u, const float* h, const float* a, const float* stats, const float* gamma,
+                        const float* beta, float* d, float* stats_b, float* pg, float* pb, int pld, void* ws1,
+                        long long ws1_bytes, int N, int C, int HW, float* amax, hipStream_t st);
 /* tangent (JVP) of the same block: hd from the tangent t of a; stats_t = (mean t, mean xhat*t). */
 int pgan_gn_jvp(const float* t, const float* h, const float* a, const float* stats, const float* gamma, const float* beta,
                 float* hd, float* stats_t, void* ws, long long ws_bytes, int N, int C, int HW, float* amax, hipStream_t st);

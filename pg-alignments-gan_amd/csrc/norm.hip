@@ -245,6 +245,190 @@ __global__ __launch_bounds__(ST) void gn_bwd_apply(const float* __restrict__ u, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-launch forms.  A slice (an eighth of a sample) is at most 32 elements per thread and tensor, so a block can keep
+// what it read for the sums in registers and apply from there: every input is read once instead of twice.  What the
+// eight blocks of a sample must exchange in between are their partial sums (2-3 doubles each).  They do that through
+// 64-bit slots in device memory that hold a sentinel (all ones: a NaN pattern no sum produces, see publish) between
+// launches: a block stores its partials into its slots with device-scope atomic stores and polls the sample's slots
+// with device-scope atomic loads until none holds the sentinel -- every slot is its own flag, so no ordering between
+// different addresses is needed.  The last block of a sample to finish reading (a per-sample counter) puts the
+// sentinels back, so every launch leaves the workspace as it found it.
+//   Blocks of one sample are adjacent in launch order (and land on one XCD when N is a multiple of 8, see
+// onepass_block), blocks are dispatched in order, and a block that waits only waits for blocks launched at most seven
+// positions after it: the earliest sample with a block still waiting always has its missing blocks at the head of the
+// dispatch queue, so the waits end.  They are bounded all the same: after SPIN_LIMIT polls a block stops waiting, sets
+// the workspace's error word and finishes with whatever it read, so that a broken workspace shows as wrong numbers and
+// a flag rather than as a hung device.
+//   The arithmetic, its order and therefore the bits of every result equal those of the sums / apply pair.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long SENTINEL = ~0ull;
+constexpr int SPIN_LIMIT = 1 << 22;
+constexpr int NVMAX = 3;
+// workspace: a 64-byte header (word 0: error flag) and one 200-byte record per sample -- SL * NVMAX slots and the
+// sample's counter -- so that the layout does not depend on how many samples a call has
+constexpr int REC = SL * NVMAX + 1;      // 64-bit words per sample
+struct OnePassWs {
+    unsigned long long* rec;     // [capacity][REC]
+    unsigned int* error;
+    __device__ unsigned long long* slots(int n) const { return rec + (size_t)n * REC; }
+    __device__ unsigned int* done(int n) const { return reinterpret_cast<unsigned int*>(rec + (size_t)n * REC + SL * NVMAX); }
+};
+__host__ __device__ inline long long onepass_bytes(int N) { return 64 + (long long)N * REC * 8; }
+inline OnePassWs onepass_ws(void* ws) {
+    OnePassWs w;
+    w.error = static_cast<unsigned int*>(ws);
+    w.rec = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 64);
+    return w;
+}
+// (sample, slice) of this block: with N a multiple of 8 the eight slices of a sample are eight blocks whose indices are
+// equal mod 8 -- blocks are dealt to the 8 XCDs round-robin, so a sample's exchange stays inside one XCD's L2 and its
+// blocks are neighbours in that XCD's dispatch order; otherwise consecutive blocks.
+__device__ __forceinline__ void onepass_block(int N, int& n, int& s) {
+    const int b = blockIdx.x;
+    if ((N & 7) == 0) {
+        const int x = b & 7, j = b >> 3;
+        n = (j >> 3) * 8 + x;
+        s = j & 7;
+    } else {
+        n = b / SL;
+        s = b % SL;
+    }
+}
+struct SliceAt : Slice {
+    __device__ SliceAt(int M, int C, int n_, int s_) : Slice(M, C) {
+        n = n_; s = s_;
+        base = (int64_t)n * M + (int64_t)s * (M / SL);
+        c0 = s * (C / SL);
+    }
+};
+// Block sums of red[] -> the sample's totals in tot[], through the slots (see above).  shv: SL * NV doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void exchange_partials(double (&red)[NV], double (&tot)[NV], double* sh, double* shv,
+                                                  const OnePassWs& w, const Slice& sl) {
+    block_sum<NV>(red, sh);
+    unsigned long long* mine = w.slots(sl.n);
+    if (sl.tid == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned long long bits = __builtin_bit_cast(unsigned long long, red[i]);
+            if (bits == SENTINEL) bits ^= 1ull;            // still a NaN, no longer the sentinel
+            __hip_atomic_store(mine + sl.s * NVMAX + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (sl.tid < SL * NV) {
+        const int s = sl.tid / NV, i = sl.tid % NV;
+        unsigned long long bits = SENTINEL;
+        int polls = 0;
+        while (true) {
+            bits = __hip_atomic_load(mine + s * NVMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits != SENTINEL || ++polls >= SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (bits == SENTINEL) __hip_atomic_store(w.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        shv[sl.tid] = __builtin_bit_cast(double, bits);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = 0.0;
+        for (int s = 0; s < SL; ++s) t += shv[s * NV + i];
+        tot[i] = t;
+    }
+    // every poll of this block has returned (the barrier above): count it; the sample's last block restores the slots
+    if (sl.tid == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(w.done(sl.n), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == SL - 1) {
+            for (int k = 0; k < SL * NVMAX; ++k)
+                __hip_atomic_store(mine + k, SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w.done(sl.n), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__global__ void onepass_init_kernel(unsigned int* header, unsigned long long* rec, long long nwords) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) header[i] = 0u;
+    if (i < nwords) rec[i] = (i % REC == SL * NVMAX) ? 0ull : SENTINEL;
+}
+
+// first-order backward in one launch: gn_bwd_sums and gn_bwd_apply on the same registers.  Q = float4 per thread and tensor.
+template <bool MA, int GL, int Q>
+__global__ __launch_bounds__(ST) void gn_bwd_onepass(const float* __restrict__ u, const float* __restrict__ h,
+                                                     const float* __restrict__ a, const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ d, float* __restrict__ stats_b,
+                                                     float* __restrict__ pg, float* __restrict__ pb, OnePassWs w, int N,
+                                                     int M, int HW, int C, int pld, float* __restrict__ amax) {
+    __shared__ double sh[2 * ST / 64], shv[SL * 2];
+    __shared__ float cg[CW * 64], cb[CW * 64];
+    int n_, s_;
+    onepass_block(N, n_, s_);
+    const SliceAt sl(M, C, n_, s_);
+    const int cps = C / SL;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u + sl.base);
+    const f32x4* h4 = MA ? nullptr : reinterpret_cast<const f32x4*>(h + sl.base);
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a + sl.base);
+    f32x4 uv[Q], av[Q], mk[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        uv[k] = u4[sl.tid + k * ST];
+        av[k] = a4[sl.tid + k * ST];
+    }
+    const float mu = stats[2 * sl.n], r = stats[2 * sl.n + 1];
+    for (int c = sl.tid; c < CW * 64; c += ST) { cg[c] = 0.f; cb[c] = 0.f; }
+    __syncthreads();
+    float sw = 0.f, swx = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int i = sl.tid + k * ST, cl = (i * 4) / HW;
+        const float g = gamma[sl.c0 + cl], b = MA ? beta[sl.c0 + cl] : 0.f;
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!MA) hv = h4[i];
+        float pe[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[k][e] - mu) * r, m = mask_of<MA>(hv[e], g, xh, b), ee = m * uv[k][e], wv = g * ee;
+            mk[k][e] = m;
+            sw += wv;
+            swx += wv * xh;
+            pe[0] += ee * xh;
+            pe[1] += ee;
+        }
+        float* const dst[2] = {cg, cb};
+        channel_accumulate<GL, 2>(pe, dst, cl);
+    }
+    double red[2] = {sw, swx}, tot[2];
+    exchange_partials<2>(red, tot, sh, shv, w, sl);      // its barriers also order the per-wave channel rows
+    for (int c = sl.tid; c < cps; c += ST) {
+        pg[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cg, c);
+        pb[(int64_t)sl.n * pld + sl.c0 + c] = channel_total(cb, c);
+    }
+    const float mw = (float)(tot[0] / M), mwx = (float)(tot[1] / M);
+    if (sl.s == 0 && sl.tid == 0) {
+        stats_b[2 * sl.n] = mw;
+        stats_b[2 * sl.n + 1] = mwx;
+    }
+    f32x4* d4 = reinterpret_cast<f32x4*>(d + sl.base);
+    float am = 0.f;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int i = sl.tid + k * ST, c = sl.c0 + (i * 4) / HW;
+        const float g = gamma[c];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (av[k][e] - mu) * r, wv = g * mk[k][e] * uv[k][e];
+            o[e] = r * (wv - mw - xh * mwx);
+        }
+        am = amax4(am, o);
+        d4[i] = o;
+    }
+    if (amax) {      // uniform over the block
+        am = block_amax256(am);
+        if (sl.tid == 0) amax[sl.n * SL + sl.s] = am;
+    }
+}
+
 // tangent forward: hd = m gamma J t.  Primal state (h, a, stats) of sample n; stats_t = (mean t, mean xh t).
 __global__ __launch_bounds__(ST) void gn_jvp_sums(const float* __restrict__ t, const float* __restrict__ a,
                                                   const float* __restrict__ stats, double* __restrict__ ws, int M, int C) {
@@ -673,6 +857,37 @@ constexpr int MAX_DEVICES = 64;
 static __device__ __align__(256) double scratch[GN_STATIC_MAX_N * SL * 3];
 std::atomic<double*> g_scratch_ptr[MAX_DEVICES];
 
+bool onepass_shape_ok(int N, int C, int HW, const void* ws1, long long ws1_bytes, int& q) {
+    if (!(N > 0 && C > 0 && C <= 512 && C % SL == 0 && HW >= 16 && (HW & (HW - 1)) == 0 && ws1 && ws1_bytes >= onepass_bytes(N)))
+        return false;
+    const int M = C * HW;
+    if (M % (SL * 4 * ST)) return false;
+    q = M / (SL * 4 * ST);
+    return q == 1 || q == 2 || q == 4 || q == 8;
+}
+// f(ma, gl, q) with the three as compile-time constants: mask from a or from h; lanes per channel; float4 per thread
+template <typename F>
+void onepass_dispatch(bool ma, int HW, int q, F&& f) {
+    auto with_q = [&](auto ma_, auto gl_) {
+        switch (q) {
+            case 1: f(ma_, gl_, std::integral_constant<int, 1>{}); break;
+            case 2: f(ma_, gl_, std::integral_constant<int, 2>{}); break;
+            case 4: f(ma_, gl_, std::integral_constant<int, 4>{}); break;
+            default: f(ma_, gl_, std::integral_constant<int, 8>{});
+        }
+    };
+    auto with_gl = [&](auto ma_) {
+        switch (HW) {
+            case 16: with_q(ma_, std::integral_constant<int, 4>{}); break;
+            case 32: with_q(ma_, std::integral_constant<int, 8>{}); break;
+            case 64: with_q(ma_, std::integral_constant<int, 16>{}); break;
+            case 128: with_q(ma_, std::integral_constant<int, 32>{}); break;
+            default: with_q(ma_, std::integral_constant<int, 64>{});
+        }
+    };
+    if (ma) with_gl(std::true_type{});
+    else with_gl(std::false_type{});
+}
 }  // namespace
 
 extern "C" {
@@ -781,6 +996,41 @@ int pgan_gn_bwd(const float* u, const float* h, const float* a, const float* sta
         by_hw(std::false_type{});
         gn_bwd_apply<false><<<N * SL, ST, 0, st>>>(u, h, a, stats, gamma, beta, d, stats_b, w, C * HW, HW, C, amax);
     }
+    return pgan_launch_status();
+}
+
+// ---- one-launch forms (see exchange_partials).  ws1: pgan_gn_onepass_workspace_bytes(N) bytes, passed once through
+// pgan_gn_onepass_workspace_init after allocation (every call leaves it in that state); one workspace per stream, as for
+// the two-launch calls.  Shapes: C * HW / 8192 in {1, 2, 4, 8} (the four stages of the 64 x 64 networks); others return -1
+// and launch nothing -- call the two-launch form.  Results are bit-identical to the two-launch form's.
+long long pgan_gn_onepass_workspace_bytes(int N) { return N > 0 ? onepass_bytes(N) : -1; }
+int pgan_gn_onepass_workspace_init(void* ws1, long long ws1_bytes, int N, hipStream_t st) {
+    if (!ws1 || N <= 0 || ws1_bytes < onepass_bytes(N)) return PGAN_EINVAL;
+    const OnePassWs w = onepass_ws(ws1);
+    const long long nwords = (long long)N * REC;
+    onepass_init_kernel<<<(unsigned)((nwords + 255) / 256), 256, 0, st>>>(w.error, w.rec, nwords);
+    return pgan_launch_status();
+}
+// 1 if a one-launch call on this workspace ever gave up waiting (the results of that call are wrong), else 0; -2 on error.
+// Synchronises the stream.
+int pgan_gn_onepass_workspace_error(const void* ws1, int N, hipStream_t st) {
+    if (!ws1 || N <= 0) return PGAN_EINVAL;
+    const OnePassWs w = onepass_ws(const_cast<void*>(ws1));
+    unsigned int e = 0;
+    if (hipMemcpyAsync(&e, w.error, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return PGAN_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return PGAN_ELAUNCH;
+    return e ? 1 : 0;
+}
+int pgan_gn_bwd_onepass(const float* u, const float* h, const float* a, const float* stats, const float* gamma,
+                        const float* beta, float* d, float* stats_b, float* pg, float* pb, int pld, void* ws1,
+                        long long ws1_bytes, int N, int C, int HW, float* amax, hipStream_t st) {
+    int q = 0;
+    if (!onepass_shape_ok(N, C, HW, ws1, ws1_bytes, q) || pld < C || (!beta && !h)) return PGAN_EINVAL;
+    const OnePassWs w = onepass_ws(ws1);
+    onepass_dispatch(beta != nullptr, HW, q, [&](auto ma, auto gl, auto qq) {
+        gn_bwd_onepass<decltype(ma)::value, decltype(gl)::value, decltype(qq)::value><<<N * SL, ST, 0, st>>>(
+            u, h, a, stats, gamma, beta, d, stats_b, pg, pb, w, N, C * HW, HW, C, pld, amax);
+    });
     return pgan_launch_status();
 }
 

@@ -66,7 +66,7 @@ const Entry ENTRIES[] = {
     PGAN_ENTRY(pgan_conv_h2_prep), PGAN_ENTRY(pgan_conv_h2_prep_multi), PGAN_ENTRY(pgan_conv_h2_forget),
     PGAN_ENTRY(pgan_conv_down_h2), PGAN_ENTRY(pgan_conv_up_h2), PGAN_ENTRY(pgan_conv_wgrad_h2),
     PGAN_ENTRY(pgan_gn_fwd), PGAN_ENTRY(pgan_gn_fwd_presummed), PGAN_ENTRY(pgan_gn_fwd_static), PGAN_ENTRY(pgan_gn_bwd),
-    PGAN_ENTRY(pgan_gn_jvp), PGAN_ENTRY(pgan_gn_bwd2),
+    PGAN_ENTRY(pgan_gn_jvp), PGAN_ENTRY(pgan_gn_bwd2), PGAN_ENTRY(pgan_gn_bwd_onepass),
     PGAN_ENTRY(pgan_bn_fwd), PGAN_ENTRY(pgan_bn_bwd), PGAN_ENTRY(pgan_bn_fwd_sums), PGAN_ENTRY(pgan_bn_fwd_apply),
     PGAN_ENTRY(pgan_bn_bwd_sums), PGAN_ENTRY(pgan_bn_bwd_apply),
     PGAN_ENTRY(pgan_head_fwd), PGAN_ENTRY(pgan_head_seed), PGAN_ENTRY(pgan_head_wgrad),

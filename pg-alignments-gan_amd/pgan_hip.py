@@ -64,6 +64,10 @@ _SIGS = {
     "pgan_gn_fwd": [P, P, P, P, P, P, L, I, I, I, P, P],
     "pgan_gn_fwd_presummed": [P, P, P, P, P, P, L, I, I, I, P, P],
     "pgan_gn_bwd": [P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
+    "pgan_gn_bwd_onepass": [P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
+    "pgan_gn_onepass_workspace_bytes": [I],
+    "pgan_gn_onepass_workspace_init": [P, L, I, P],
+    "pgan_gn_onepass_workspace_error": [P, I, P],
     "pgan_rows_reduce_multi": [P, P, P, P, I, I, I, I, I, P],
     "pgan_gn_jvp": [P, P, P, P, P, P, P, P, P, L, I, I, I, P, P],
     "pgan_gn_bwd2": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P, L, I, I, I, P, P],
@@ -144,6 +148,7 @@ _lib.pgan_gn_fwd_static_init.argtypes = []
 _lib.pgan_gn_fwd_static_init.restype = c_int
 _lib.pgan_gn_workspace_bytes.argtypes = [I]
 _lib.pgan_gn_workspace_bytes.restype = c_longlong
+_lib.pgan_gn_onepass_workspace_bytes.restype = c_longlong
 _lib.pgan_events_created.argtypes = []
 _lib.pgan_events_created.restype = c_longlong
 _lib.pgan_tape_create.argtypes = []
@@ -185,7 +190,8 @@ class _Lib:
     pass through untouched)."""
     _HOST = ("pgan_parse_alignments", "pgan_parse_ms", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
              "pgan_step_graph_destroy", "pgan_event_create", "pgan_event_destroy", "pgan_tape_destroy", "pgan_tape_arg_count",
-             "pgan_tape_append", "pgan_tape_length", "pgan_tape_replay")
+             "pgan_tape_append", "pgan_tape_length", "pgan_tape_replay", "pgan_gn_onepass_workspace_bytes",
+             "pgan_gn_onepass_workspace_init", "pgan_gn_onepass_workspace_error")
 
     def __init__(self, lib):
         self._real = lib
@@ -414,6 +420,8 @@ class HipOps:
         # partial sums another chain's apply launch is about to read.  Streams are registered up front
         # (reserve_stream); a stream first seen while a capture is open is an error, not an allocation.
         self._gn_bytes = int(_lib.pgan_gn_workspace_bytes(4 * max_samples))
+        self._gn1_samples = 4 * max_samples
+        self._gn1_bytes = int(_lib.pgan_gn_onepass_workspace_bytes(self._gn1_samples))
         self._bn_bytes = int(_lib.pgan_bn_workspace_bytes(512))
         self._scratch = {}
         self.capturing = False
@@ -613,10 +621,15 @@ class HipOps:
     def reserve_stream(self, handle: int) -> None:
         """Allocate the norm-kernel scratch of a stream (raw handle) before work is enqueued on it."""
         if handle not in self._scratch:
-            if self.capturing:
-                raise PganError("a stream without reserved scratch was used inside a graph capture")
+            if self.capturing or pgan_tape.tape is not None:
+                raise PganError("a stream without reserved scratch was used inside a graph capture or a tape recording")
+            one = torch.empty(self._gn1_bytes, dtype=torch.uint8, device=self.device)
+            # the one-launch GroupNorm calls exchange partial sums through this buffer: initialised once, restored by every call
+            _check(_lib.pgan_gn_onepass_workspace_init(one.data_ptr(), self._gn1_bytes, self._gn1_samples, _stream()),
+                   "pgan_gn_onepass_workspace_init")
+            torch.cuda.current_stream().synchronize()
             self._scratch[handle] = (torch.empty(self._gn_bytes, dtype=torch.uint8, device=self.device),
-                                     torch.empty(self._bn_bytes, dtype=torch.uint8, device=self.device))
+                                     torch.empty(self._bn_bytes, dtype=torch.uint8, device=self.device), one)
 
     def _gnws(self):
         """Slice-sum scratch of the GroupNorm kernels for the current stream."""
@@ -626,6 +639,33 @@ class HipOps:
             self.reserve_stream(key)
             ent = self._scratch[key]
         return ent[0].data_ptr(), self._gn_bytes
+
+    # PGAN_GN_ONEPASS=1: the GroupNorm backward of the two large stages in one launch (pgan_gn_bwd_onepass) instead of the
+    # sums / apply pair; =2: of every stage the one-launch kernel supports.  Bit-identical results; measured a few percent
+    # faster per call on the large stages, slower on the small ones, nothing on the whole iteration: off by default.
+    gn_onepass = int(os.environ.get("PGAN_GN_ONEPASS", "0"))
+
+    def _gnws1(self):
+        """Exchange workspace of the one-launch GroupNorm kernels for the current stream."""
+        key = _stream()
+        ent = self._scratch.get(key)
+        if ent is None:
+            self.reserve_stream(key)
+            ent = self._scratch[key]
+        return ent[2].data_ptr(), self._gn1_bytes
+
+    def gn_onepass_error(self) -> bool:
+        """True if a one-launch GroupNorm call on any stream of this backend ever gave up waiting (synchronises)."""
+        bad = False
+        for ent in self._scratch.values():
+            rc = _lib.pgan_gn_onepass_workspace_error(ent[2].data_ptr(), self._gn1_samples, _stream())
+            _check(min(rc, 0), "pgan_gn_onepass_workspace_error")
+            bad = bad or rc == 1
+        return bad
+
+    def _onepass_shape(self, a) -> bool:
+        m = a.shape[1] * _hw(a)
+        return m % 8192 == 0 and m // 8192 in ((4, 8) if self.gn_onepass == 1 else (1, 2, 4, 8))
 
     def _bnws(self):
         """Slice-sum scratch of the BatchNorm kernels for the current stream."""
@@ -688,6 +728,11 @@ class HipOps:
     def gn_bwd(self, u, h, a, stats, gamma, d, stats_b, pg, pb, amax=None, beta=None):
         """beta (gn_bwd, gn_jvp, gn_bwd2): given, the LeakyReLU mask is recomputed from a and h is not read."""
         N, C = a.shape[0], a.shape[1]
+        if self.gn_onepass and self._onepass_shape(a) and N <= self._gn1_samples:
+            _check(_lib.pgan_gn_bwd_onepass(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(d),
+                                            _ptr(stats_b), _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws1(), N, C,
+                                            _hw(a), _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd_onepass")
+            return
         _check(_lib.pgan_gn_bwd(_ptr(u), _ptr(h), _ptr(a), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(d), _ptr(stats_b),
                                 _rows_ptr(pg), _rows_ptr(pb), pg.stride(0), *self._gnws(), N, C, _hw(a),
                                 _amax_out(amax, N * GN_AMAX_SLOTS), _stream()), "pgan_gn_bwd")

@@ -876,3 +876,42 @@ def test_step_graph_capture_and_replay(hip):
     close("graph.y", y, (2 * want + 3).double().cpu())
     close("graph.z", z, (1 - want).double().cpu())
     del g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [3, 8, 64])
+def test_groupnorm_backward_in_one_launch_equals_the_two_launch_form(N):
+    """pgan_gn_bwd_onepass (a block keeps its eighth of a sample in registers between the sums and the apply part; the
+    eight blocks of a sample exchange their partial sums through device memory inside the launch) gives the bits of
+    pgan_gn_bwd on the four stage shapes, with sample counts that are and are not multiples of eight (two block
+    orders), repeatedly on one workspace (every call must leave it as it found it), and never gives up waiting."""
+    from pgan_hip import HipOps
+    dev = torch.device("cuda:0")
+    o = HipOps(dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    for C, H in ((64, 32), (128, 16), (256, 8), (512, 4)):
+        a, u = rnd(N, C, H, H), rnd(N, C, H, H)
+        gamma, beta = 1 + 0.1 * rnd(C), 0.1 * rnd(C)
+        h, stats = torch.empty_like(a), torch.empty(N, 2, device=dev)
+        o.gn_fwd(a, gamma, beta, h, stats)
+        got = {}
+        for mode in (0, 2, 2):
+            o.gn_onepass = mode
+            out = dict(d=torch.full_like(a, float("nan")), sb=torch.full((N, 2), float("nan"), device=dev),
+                       pg=torch.full((N, C), float("nan"), device=dev), pb=torch.full((N, C), float("nan"), device=dev),
+                       am=torch.full((N, 8), float("nan"), device=dev))
+            for use_h in (False, True):      # mask recomputed from a (beta given) and read from h
+                o.gn_bwd(u, h if use_h else None, a, stats, gamma, out["d"], out["sb"], out["pg"], out["pb"], amax=out["am"],
+                         beta=None if use_h else beta)
+                torch.cuda.synchronize()
+                key = (mode > 0, use_h)
+                if key in got:
+                    for k, v in out.items():
+                        assert torch.equal(v, got[key][k]), (C, H, k, "second call on the same workspace")
+                got[key] = {k: v.clone() for k, v in out.items()}
+        for use_h in (False, True):
+            for k in got[(False, use_h)]:
+                assert torch.isfinite(got[(True, use_h)][k]).all(), (C, H, k)
+                assert torch.equal(got[(False, use_h)][k], got[(True, use_h)][k]), (C, H, k, use_h)
+    assert not o.gn_onepass_error()
