@@ -462,7 +462,10 @@ def main():
     tr.iteration()
     timed.recording = False
     torch.cuda.synchronize()
-    summ = timed.time_shapes(args.profile_iters, stream=getattr(tr.eng.side, "stream", None))
+    # the per-shape launches are captured into a graph on an idle stream of the engine -- except under a process group:
+    # RCCL's watchdog thread polls the events of finished collectives, which were recorded on the engine's streams, and HIP
+    # refuses a query of an event whose stream is capturing (the capture is then invalidated): a fresh stream there
+    summ = timed.time_shapes(args.profile_iters, stream=None if pg is not None else getattr(tr.eng.side, "stream", None))
 
     if rank == 0:
         conv = {k: v for k, v in summ.items() if k[0].startswith("conv_")}
