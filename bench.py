@@ -311,6 +311,10 @@ def main():
     ap.add_argument("--local-bn", action="store_true",
                     help="several GPUs: BatchNorm statistics per GPU instead of over the global batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of a multi-rank run: nccl (= RCCL, the measured configuration) or gloo -- a "
+                         "rehearsal of the multi-rank control flow where the ranks have to share GPUs (collectives staged "
+                         "through host memory; ranks beyond the visible devices wrap around)")
     ap.add_argument("--profile-iters", type=int, default=20, help="back-to-back launches per shape for per-kernel timing")
     ap.add_argument("--no-fp32-pipe", action="store_true", help="skip the side measurement with every convolution on the fp32 matrix pipe")
     ap.add_argument("--kernels-only", action="store_true",
@@ -343,7 +347,7 @@ def main():
         args.batch, scaling = gb // world, "strong"
     elif args.batch is None:
         args.batch = cfg["batch"]
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1) if args.dist_backend != "nccl" else local)
     torch.cuda.set_device(dev)
     pg = None
     use_dist = world > 1 or bool(os.environ.get("PGAN_FORCE_DIST"))   # PGAN_FORCE_DIST: exercise the RCCL path on one GPU
@@ -390,7 +394,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
         tr.attach_process_group(pg, sync_bn=not args.local_bn)
 
@@ -406,6 +413,13 @@ def main():
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
+
+    def max_over_ranks(values):
+        """element-wise maximum of a few host numbers over the ranks"""
+        import torch.distributed as dist
+        t = torch.tensor(values, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
 
     routes = {}
     if args.route in ("auto", "eager"):
@@ -425,10 +439,7 @@ def main():
         raise SystemExit(f"--route {args.route} is not available here")
     times = {k: rate(fn) for k, fn in routes.items()}
     if world > 1:      # every rank takes the same route: the slowest rank's timing decides
-        import torch.distributed as dist
-        tt = torch.tensor([times[k] for k in sorted(times)], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        times = dict(zip(sorted(times), tt.tolist()))
+        times = dict(zip(sorted(times), max_over_ranks([times[k] for k in sorted(times)])))
     best = min(times, key=times.get)
     step, use_graph = routes[best], best == "graph"
     route = best + " (calibration, ms per iteration: " + ", ".join(f"{k} {v * 1e3:.2f}" for k, v in sorted(times.items())) + ")"
@@ -451,10 +462,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        dt = max_over_ranks([dt])[0]
     losses = tr.losses()
 
     # per-kernel timing: note one iteration's launches, then time each launch shape on its own
