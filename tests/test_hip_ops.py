@@ -915,3 +915,42 @@ def test_groupnorm_backward_in_one_launch_equals_the_two_launch_form(N):
                 assert torch.isfinite(got[(True, use_h)][k]).all(), (C, H, k)
                 assert torch.equal(got[(False, use_h)][k], got[(True, use_h)][k]), (C, H, k, use_h)
     assert not o.gn_onepass_error()
+
+
+@pytest.mark.parametrize("Cs,Cl,hs", LAYERS + [(64, 1, 32)])
+@pytest.mark.parametrize("N", [64, 128, 320])
+@pytest.mark.parametrize("precision", ["h2", "x3", "fp32"])
+def test_convolutions_at_bench_sizes(Cs, Cl, hs, N, precision):
+    """The launch shapes of the benchmark (64- and 128-sample chains, the 320-sample batched generator forward) choose
+    other tiles, K splits and block orders than the small cases above.  Checked there through what needs no oracle at
+    that size -- DOWN, UP and WGRAD are the three partial derivatives of one trilinear form T(x, w, y) = <conv(x, w), y>,
+    so <DOWN(x, w), y> = <x, UP(y, w)> = <WGRAD(y, x), w> -- and against the fp64 statement on the first and last two
+    samples of the batch (tile edges)."""
+    from pgan_hip import HipOps
+    o = HipOps(torch.device(DEV), precision=precision, max_samples=2048)
+    g = torch.Generator(device="cpu").manual_seed(100 + hs + N)
+    x = torch.randn(N, Cl, 2 * hs, 2 * hs, generator=g).to(DEV)
+    y = torch.randn(N, Cs, hs, hs, generator=g).to(DEV)
+    w = (torch.randn(Cs, Cl, 4, 4, generator=g) * 0.05).to(DEV)
+    dx = torch.full_like(y, float("nan"))
+    uy = torch.full_like(x, float("nan"))
+    dw = torch.full_like(w, float("nan"))
+    o.conv_down(x, w, dx)
+    o.conv_up(y, w, uy)
+    o.conv_wgrad(y, x, dw)
+    torch.cuda.synchronize()
+    t_down = float((dx.double() * y.double()).sum())
+    t_up = float((uy.double() * x.double()).sum())
+    t_wg = float((dw.double() * w.double()).sum())
+    scale = float(dx.double().norm() * y.double().norm())
+    print(f"{precision} N={N} Cs={Cs} Cl={Cl} hs={hs}: T = {t_down:.6e} / {t_up:.6e} / {t_wg:.6e}, scale {scale:.3e}")
+    assert abs(t_down - t_up) <= 1e-5 * scale and abs(t_down - t_wg) <= 1e-5 * scale
+    edge = torch.tensor([0, 1, N - 2, N - 1])
+    xe, ye = x[edge].cpu().double(), y[edge].cpu().double()
+    want_d = torch.nn.functional.conv2d(xe, w.cpu().double(), stride=2, padding=1)
+    want_u = torch.nn.functional.conv_transpose2d(ye, w.cpu().double(), stride=2, padding=1)
+    close("conv_down, edge samples", dx[edge], want_d)
+    close("conv_up, edge samples", uy[edge], want_u)
+    # the weight gradient over the whole batch against fp64 on the device
+    want_w = torch.nn.grad.conv2d_weight(x.double(), w.shape, y.double(), stride=2, padding=1)
+    close("conv_wgrad", dw, want_w.cpu())
