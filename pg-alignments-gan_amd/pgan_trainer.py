@@ -68,7 +68,7 @@ class FusedTrainer:
             inside = [n for n in store.offsets if lo <= store.offsets[n] < hi]
             if sorted(inside) == sorted(names):
                 self.early_buckets[trigger] = (store, lo, hi)
-        self.dist_active, self.sync_bn, self._drain = False, False, False
+        self.dist_active, self.sync_bn, self._drain_known = False, False, None
         if world > 1 or process_group is not None:
             self.attach_process_group(process_group, sync_bn)
         # Philox state: (seed lo, seed hi, offset lo, offset hi); ranks with streams of their own differ in the seed's
@@ -131,8 +131,8 @@ class FusedTrainer:
         # tensors to the backend: gloo's own device staging (copies on streams of its own, completed from a helper
         # thread) was seen to stall two ranks that share one GPU, both between the engine's four busy streams and at
         # the end of a long-lived test process.
-        import torch.distributed as dist
-        self._drain = self.dev.type == "cuda" and dist.is_initialized() and dist.get_backend(process_group) != "nccl"
+        # Decided at the first collective: the trainer may be attached before torch.distributed is initialised.
+        self._drain_known = None
         # collectives run on "the current stream": a launch tape replays them under the stream they were issued on
         self.eng.grad_ready = lambda name: pgan_tape.call(self._early_reduce, name, on_current_stream=True)
         self.eng.gen_grad_ready = lambda name: pgan_tape.call(self._early_reduce_g, name, on_current_stream=True)
@@ -284,6 +284,16 @@ class FusedTrainer:
     def _reduce(self, flat: torch.Tensor) -> None:
         if self.dist_active:
             pgan_tape.call(self._allreduce, flat, on_current_stream=True)
+
+    @property
+    def _drain(self) -> bool:
+        """Collectives staged through host memory: every backend but RCCL on device tensors."""
+        if self._drain_known is None:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("a data-parallel trainer needs torch.distributed initialised before its first step")
+            self._drain_known = self.dev.type == "cuda" and dist.get_backend(self.pg) != "nccl"
+        return self._drain_known
 
     def _sum_over_ranks(self, t: torch.Tensor, async_op: bool = False):
         """all-reduce(sum) of a device tensor in place: on the device over RCCL, through host memory otherwise."""

@@ -282,3 +282,35 @@ def test_bench_runs_under_the_launcher_with_several_ranks(ranks, tmp_path):
     assert out["n_gpus"] == ranks and out["value"] > 0 and out["roofline"]["frac"] > 0
     assert out["config"]["global_batch"] == 64 * ranks and out["scaling"] == "weak"
     assert all(np.isfinite(v) for v in out["losses"].values())
+
+
+def test_command_line_trainer_under_the_launcher_with_two_ranks(tmp_path):
+    """train_wgan_v2.py as `python -m torch.distributed.run --nproc-per-node 2` runs it (the two ranks share this box's GPU;
+    collectives over gloo): --batch_size stays the global batch, every rank loads the whole pool and takes its rows of
+    every global batch, rank 0 writes the checkpoints, and the replicas' weights are the same numbers at the end."""
+    import ast
+    import subprocess
+    from test_hip_cli import _write_sims
+    idir, odir = tmp_path / "sims", tmp_path / "out"
+    idir.mkdir()
+    _write_sims(str(idir), 96)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PGAN_DIST_BACKEND="gloo", PGAN_DUMP_WEIGHT_SUMS=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "pg-alignments-gan_amd", "train_wgan_v2.py"), "--idir", str(idir),
+           "--odir", str(odir), "--use_cuda", "--num_in", "96", "--batch_size", "16", "--epochs", "2", "--save_freq", "1",
+           "--critic_iter", "2", "--label_smooth", "--mono_switch"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    dumps = [[ast.literal_eval(l) for l in open(tmp_path / f"weights_rank{r}.txt")] for r in (0, 1)]
+    # the weights; the generator's running statistics differ by design: only rank 0 makes the 1000-sample plotting forward
+    # before a save (src/train_wgan_v2.py:686-698), which steps them, and training never reads them
+    assert dumps[0][0] == dumps[1][0], dumps
+    assert all(np.isfinite(v) for d_ in dumps for row in d_ for v in row)
+    g = torch.load(odir / "generator_model_0002.pt", weights_only=True)
+    d = torch.load(odir / "discriminator_model_0002.pt", weights_only=True)
+    assert all(bool(torch.isfinite(v.float()).all()) for v in list(g.values()) + list(d.values()))
+    # 96 alignments / (global batch 16) / 2 critic steps = 3 iterations per epoch, 3 generator passes each, + 2 plotting forwards
+    assert int(g["twod_conv_layers.1.num_batches_tracked"]) == 2 * 3 * 3 + 2
