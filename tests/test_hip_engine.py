@@ -637,15 +637,16 @@ def test_scaled_128_trainer_routes_agree(hip):
             assert rel_err(out[route][k], out["eager"][k]) < 1e-3, (route, k)
 
 
-@pytest.mark.parametrize("loss,sync_bn", [("gp", False), ("div", False), ("gp", True)])
-def test_operand_bounds_hold_in_every_split_convolution(hip, loss, sync_bn, monkeypatch):
+@pytest.mark.parametrize("loss,sync_bn,data", [("gp", False, 64), ("div", False, 64), ("gp", True, 64), ("gp", False, 128),
+                                               ("div", True, 128)])
+def test_operand_bounds_hold_in_every_split_convolution(hip, loss, sync_bn, data, monkeypatch):
     """The fp16-split convolutions trust the magnitude bounds their producers report (a bound below the truth could
     overflow fp16 silently).  With the backend's checking mode on, every bounded convolution of a critic step and a
     generator step -- forward, both backward passes, tangent pass, weight gradients; BatchNorm statistics in one launch
     and as the data-parallel sums / apply pair -- compares its bounds with the operand's true magnitudes first."""
     from pgan_hip import HipOps
-    B, seed = 8, 99
-    eng, gp_, dp = make_engine(hip, B, loss, "sigmoid", seed)
+    B, seed = (8 if data == 64 else 4), 99
+    eng, gp_, dp = make_engine(hip, B, loss, "sigmoid", seed, data=data)
     if sync_bn:
         eng.bn_sync = lambda part: None          # one rank's share is the whole batch: the sums are already global
     # weights far from their initial scale, so that the magnitudes differ by orders between stages
@@ -656,12 +657,12 @@ def test_operand_bounds_hold_in_every_split_convolution(hip, loss, sync_bn, monk
     eng.ops.invalidate_weight_planes(reset=True)
     monkeypatch.setattr(HipOps, "check_bounds", True)
     before = HipOps.bounds_checked
-    rs, rp = orc.synthetic_alignments(B, seed + 3)
+    rs, rp = orc.synthetic_alignments(B, seed + 3, size=data)
     eng.critic_grads(rs.to(DEV), rp.to(DEV), z_draw(seed + 2, B).to(DEV), t_draw(seed + 4, B).to(DEV))
     eng.generator_grads(z_draw(seed + 5, B).to(DEV))
     torch.cuda.synchronize()
     made = HipOps.bounds_checked - before
-    print(f"{loss}, sync_bn={sync_bn}: {made} bounds compared with their operands")
+    print(f"{loss}, sync_bn={sync_bn}, {data} x {data}: {made} bounds compared with their operands")
     assert made >= 30, made
     assert torch.isfinite(eng.D.gflat).all() and torch.isfinite(eng.G.gflat).all()
 
@@ -679,3 +680,30 @@ def test_bound_check_catches_a_bound_below_the_operand(hip, monkeypatch):
     with pytest.raises(PganError, match="below the operand"):
         hip.conv_down(x, w, y, bound=bad)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("loss", ["gp", "div"])
+def test_operand_bounds_hold_through_a_whole_iteration(loss, monkeypatch):
+    """The same check over the trainer's own iteration, launched eagerly: the batched generator forwards (several passes in
+    one launch per layer, whose per-channel bounds are combined over the passes), the two sample chains of a critic step
+    on their streams, five critic steps and the generator step with weights that move between them."""
+    from pgan_hip import HipOps
+    from pgan_trainer import FusedTrainer
+    ops = HipOps(torch.device(DEV))
+    tr = FusedTrainer(ops, 8, torch.device(DEV), loss=loss, critic_iter=5, seed=31)
+    tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
+    tr.eng.G.load(orc.make_params(orc.gen_param_shapes(), 8))
+    tr.weights_changed()
+    rs, rp = orc.synthetic_alignments(96, 9)
+    tr.set_pool(rs, rp)
+    tr.iteration()
+    torch.cuda.synchronize()
+    monkeypatch.setattr(HipOps, "check_bounds", True)
+    before = HipOps.bounds_checked
+    for _ in range(2):
+        tr.iteration()
+    torch.cuda.synchronize()
+    made = HipOps.bounds_checked - before
+    print(f"{loss}: {made} bounds compared with their operands in two iterations")
+    assert made >= 200, made
+    assert all(np.isfinite(v) for v in tr.losses())
