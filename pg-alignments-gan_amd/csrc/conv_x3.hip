@@ -511,6 +511,12 @@ __device__ __forceinline__ int lds_group_pixel(int j) {
 // group-wise order every 16-lane store chunk touched two rows and the kernel lost 6 %.)
 // Tap kh feeds output-row phase PH[kh] from S row a + DH[kh]:  kh 0:(1,+1) 1:(0,0) 2:(1,0) 3:(0,-1).
 // ------------------------------------------------------------------------------------------------
+// PGAN_ABL_UP (debugging builds only, results are wrong): leave out parts of the UP kernel's main loop -- 1 the MFMAs, 2 the
+// weight-fragment loads, 4 the staging of the next K steps (global loads, split, LDS stores), 8 the barrier per K step
+// (only together with 4).
+#ifndef PGAN_ABL_UP
+#define PGAN_ABL_UP 0
+#endif
 template <int HS, int BN, int NC>
 __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl,
@@ -614,7 +620,13 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     // (about 400 cycles) at one or two waves per SIMD -- less than an L2 round trip under load, and the waves sat parked
     // on s_waitcnt vmcnt for half of their cycles (hs = 4: 49-59 % by the SQ counters); two register sets, used in turn,
     // double the cover for 32 more registers.  The wider tiles run 24-48 MFMAs per K step and have no registers to spare.
-    constexpr int PD = (BN == 32) ? 2 : 1;
+#ifndef PGAN_UP_PD32
+#define PGAN_UP_PD32 2
+#endif
+#ifndef PGAN_UP_PD64
+#define PGAN_UP_PD64 1
+#endif
+    constexpr int PD = (BN == 32) ? PGAN_UP_PD32 : (BN == 64 ? PGAN_UP_PD64 : 1);
     u32x4 a[PD][4][NPL];
     auto aload = [&](auto d, int t, int ks) {         // weight fragments of tap t, K step ks, into register set d
         constexpr int D = decltype(d)::value;
@@ -659,12 +671,22 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 #pragma unroll
                         for (int i = 0; i < NPL; ++i) bo[tn][i] = *reinterpret_cast<const u32x4*>(Bs + i * BPL + bofs[t][tn]);
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) mfma_x3(a[D][t], bo[tn], acc[tn], acl[tn]);
-                    aload(d, t, knext);
-                    if (t == 0 && kc + 1 < nk) lstore(Bn);                       // K step kc+1: registers -> other buffer
-                    if (t == 1 && kc + 2 < nk) gload((k0 + kc + 2) * 16);        // K step kc+2: global -> registers
+                    for (int tn = 0; tn < TN; ++tn) {
+                        if constexpr (PGAN_ABL_UP & 1) {      // (debugging builds) operands folded into the sums, no MFMA
+#pragma unroll
+                            for (int i = 0; i < NPL; ++i)
+                                acc[tn][i] += __builtin_bit_cast(float, (a[D][t][i][0] + bo[tn][i][0]) & 0x3fffffffu);
+                        } else {
+                            mfma_x3(a[D][t], bo[tn], acc[tn], acl[tn]);
+                        }
+                    }
+                    if constexpr (!(PGAN_ABL_UP & 2)) aload(d, t, knext);
+                    if constexpr (!(PGAN_ABL_UP & 4)) {
+                        if (t == 0 && kc + 1 < nk) lstore(Bn);                       // K step kc+1: registers -> other buffer
+                        if (t == 1 && kc + 2 < nk) gload((k0 + kc + 2) * 16);        // K step kc+2: global -> registers
+                    }
                 }
-                __syncthreads();
+                if constexpr (!(PGAN_ABL_UP & 8)) __syncthreads();
             }
         });
     }
