@@ -15,11 +15,12 @@ g = torch.Generator().manual_seed(2)
 tags = sys.argv[1:] or ["21", "31", "41", "42"]
 libs = {}
 for t in tags:
-    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_pk", f"libconv_h2_pd{t}.so"))
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_pk", f"libconv_h2_{os.environ.get('PREFIX', 'pd')}{t}.so"))
     lib.pgan_conv_h2_prep_bytes.restype = LL
     lib.pgan_conv_h2_prep_bytes.argtypes = [I, I]
     lib.pgan_conv_h2_prep.argtypes = [VP, VP, I, I, VP]
     lib.pgan_conv_up_h2.argtypes = [VP, VP, VP, I, I, I, I, VP, I, I, VP]
+    lib.pgan_conv_down_h2.argtypes = [VP, VP, VP, I, I, I, I, VP, I, I, VP]
     libs[t] = lib
 st = torch.cuda.Stream()
 
@@ -42,14 +43,22 @@ for N in [int(v) for v in os.environ.get("NS", "64,128,320").split(",")]:
         y = torch.randn(N, Cs, hs, hs, generator=g).to(dev)
         w = (torch.randn(Cs, Cl, 4, 4, generator=g) * 0.05).to(dev)
         bnd = y.abs().reshape(N, 8, -1).amax(2).contiguous()
-        ref, line = None, f"UP N={N:3d} Cs={Cs} hs={hs:2d}:"
+        KIND = os.environ.get("KIND", "up")
+        xin = torch.randn(N, Cl, 2 * hs, 2 * hs, generator=g).to(dev)
+        bndx = xin.abs().reshape(N, 8, -1).amax(2).contiguous()
+        ref, line = None, f"{KIND.upper()} N={N:3d} Cs={Cs} hs={hs:2d}:"
         for t, lib in libs.items():
             planes = torch.zeros(lib.pgan_conv_h2_prep_bytes(Cs, Cl), dtype=torch.uint8, device=dev)
             x = torch.full((N, Cl, 2 * hs, 2 * hs), float("nan"), device=dev)
             with torch.cuda.stream(st):
                 assert lib.pgan_conv_h2_prep(w.data_ptr(), planes.data_ptr(), Cs, Cl, st.cuda_stream) == 0
-            call = lambda: lib.pgan_conv_up_h2(y.data_ptr(), planes.data_ptr(), x.data_ptr(), N, Cs, Cl, hs, bnd.data_ptr(), 8,
-                                               bnd.numel(), st.cuda_stream)
+            if KIND == "up":
+                call = lambda: lib.pgan_conv_up_h2(y.data_ptr(), planes.data_ptr(), x.data_ptr(), N, Cs, Cl, hs, bnd.data_ptr(), 8,
+                                                   bnd.numel(), st.cuda_stream)
+            else:
+                x = torch.full((N, Cs, hs, hs), float("nan"), device=dev)
+                call = lambda: lib.pgan_conv_down_h2(xin.data_ptr(), planes.data_ptr(), x.data_ptr(), N, Cs, Cl, hs, bndx.data_ptr(),
+                                                     8, bndx.numel(), st.cuda_stream)
             timed(call, 50)
             us = timed(call)
             torch.cuda.synchronize()
