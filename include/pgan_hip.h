@@ -72,6 +72,9 @@ int pgan_conv_x3_prep_multi(const float* const* W, void* const* planes, const in
  * below (this split ignores them; pass NULL, 0, 0). */
 int pgan_conv_down_x3(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
                       int amax_per_sample, int amax_count, hipStream_t st);
+int pgan_conv_down_x3_zeroed(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                             int amax_per_sample, int amax_count, hipStream_t st);      /* see pgan_conv_down_h2_zeroed */
+int pgan_conv_down_x3_adds(int N, int Cs, int Cl, int hs);
 int pgan_conv_up_x3(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,
                     int amax_per_sample, int amax_count, hipStream_t st);
 /* weight gradient with both operands split in the kernel (same arguments and scratch contract as pgan_conv_wgrad) */
@@ -112,6 +115,14 @@ int pgan_conv_h2_prep_multi(const float* const* W, void* const* planes, const in
                             hipStream_t st);      /* n <= 6 tensors in two launches */
 int pgan_conv_down_h2(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
                       int amax_per_sample, int amax_count, hipStream_t st);
+/* pgan_conv_down_h2 for an output that already holds zeros where the launch needs them.  A launch that splits its
+ * reduction over two blocks per output tile (small grids: pgan_conv_down_h2_adds(N, Cs, Cl, hs) == 1) adds into S and
+ * otherwise clears S first with a launch of its own in the middle of the caller's chain; a caller that clears the
+ * outputs of a whole step together beforehand (pgan_zero_multi) saves those launches.  For other shapes the call is
+ * pgan_conv_down_h2.  (_x3_zeroed / _x3_adds: the same for the bf16 split.)  Reference op as pgan_conv_down. */
+int pgan_conv_down_h2_zeroed(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                             int amax_per_sample, int amax_count, hipStream_t st);
+int pgan_conv_down_h2_adds(int N, int Cs, int Cl, int hs);
 int pgan_conv_up_h2(const float* S, const void* planes, float* L, int N, int Cs, int Cl, int hs, const float* amax,
                     int amax_per_sample, int amax_count, hipStream_t st);
 long long pgan_conv_wgrad_h2_workspace_floats(int N, int Cs, int Cl, int hs);
@@ -236,6 +247,9 @@ int pgan_sum_scale(const float* x, float* out, int n, float scale, hipStream_t s
 int pgan_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, hipStream_t st);
 /* out = x * scale + shift: torchvision Normalize(0.5, 0.5) of src/train_wgan_v2.py:453,519-521 */
 int pgan_affine(const float* x, float* out, long long n, float scale, float shift, hipStream_t st);
+/* clears n <= 16 device buffers (16-byte aligned, byte counts multiples of 16) in one launch; no reference counterpart
+ * (the outputs that pgan_conv_down_*_zeroed adds into, cleared together at the start of a step) */
+int pgan_zero_multi(void* const* bufs, const long long* bytes, int n, hipStream_t st);
 
 /* torch.optim.Adam step (src/train_wgan_v2.py:489-490,612,634) over one flat, 4-float-padded buffer.
  * step_dev != NULL: device-resident step counter, incremented then used (graph replay advances it).

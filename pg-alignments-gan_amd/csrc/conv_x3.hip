@@ -51,6 +51,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define FN_PREP_MULTI pgan_conv_h2_prep_multi
 #define FN_SET_OPTION pgan_h2_set_option
 #define FN_DOWN pgan_conv_down_h2
+#define FN_DOWN_ZEROED pgan_conv_down_h2_zeroed
+#define FN_DOWN_ADDS pgan_conv_down_h2_adds
 #define FN_UP pgan_conv_up_h2
 #define FN_WGRAD_WS pgan_conv_wgrad_h2_workspace_floats
 #define FN_WGRAD pgan_conv_wgrad_h2
@@ -62,6 +64,8 @@ constexpr bool F16 = false;
 #define FN_PREP_MULTI pgan_conv_x3_prep_multi
 #define FN_SET_OPTION pgan_x3_set_option
 #define FN_DOWN pgan_conv_down_x3
+#define FN_DOWN_ZEROED pgan_conv_down_x3_zeroed
+#define FN_DOWN_ADDS pgan_conv_down_x3_adds
 #define FN_UP pgan_conv_up_x3
 #define FN_WGRAD_WS pgan_conv_wgrad_x3_workspace_floats
 #define FN_WGRAD pgan_conv_wgrad_x3
@@ -1144,12 +1148,15 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
 
 int g_dn_order = 0;      // tuning override "down_order": 1 pixel-tile-major, 2 row-tile-major block order (0 = by size)
 // ks: 1 | 2 (blocks along K, two-addend sums) | 4 (two blocks of two wave groups each)
+// zeroed: the caller states that Y holds zeros already (K-split launches add into it); -1 only asks whether this launch
+// would need them (returns 1 / 0, launches nothing)
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
-                     const uint32_t* whdr, Bound bx) {
+                     const uint32_t* whdr, Bound bx, int zeroed) {
     if (Cs % BM || Cl % (2 * CLC * ks) || (ks != 1 && ks != 2 && ks != 4)) return PGAN_EINVAL;
     const int gy = ks > 1 ? 2 : 1;
-    if (gy > 1 && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
+    if (zeroed < 0) return gy > 1;
+    if (gy > 1 && !zeroed && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), gy);
     const int csm = g_dn_order ? g_dn_order - 1 : ((int64_t)Cs * Cl * 16 * NPL * 2 > (int64_t)N * Cl * HS * HS * 16);
     if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
@@ -1162,7 +1169,7 @@ int g_up_order = 0;                                                 // 1: pixel-
 
 template <int HS>
 int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
-                Bound bx) {
+                Bound bx, int zeroed = 0) {
     if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
     int variant = g_dn_variant, ks = g_dn_ks;
     if (variant == 0 || ks < 1) {
@@ -1180,10 +1187,10 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
     }
     if (ks == 3 || ks > 4) return PGAN_EINVAL;
     switch (variant) {
-        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
-        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
-        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
-        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx);
+        case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);
+        case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);
+        case 3: return launch_down_tile<HS, 64, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);
+        case 4: return launch_down_tile<HS, 64, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);
         default: return PGAN_EINVAL;
     }
 }
@@ -1289,20 +1296,37 @@ int FN_PREP_MULTI(const float* const* W, void* const* planes, const int* Cs, con
 }
 
 // S[N,Cs,H,H] = conv2d(L[N,Cl,2H,2H], W, stride 2, pad 1) with W given as prepared planes.  H = hs.
-int FN_DOWN(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
-            int amax_per_sample, int amax_count, hipStream_t st) {
+static int down_entry(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                      int amax_per_sample, int amax_count, hipStream_t st, int zeroed) {
     if (N <= 0) return PGAN_OK;
     const Bound bx{amax, amax_per_sample, amax_count};
-    if (!bound_ok(bx)) return PGAN_EINVAL;
+    if (zeroed >= 0 && !bound_ok(bx)) return PGAN_EINVAL;
     const uint32_t* hdr = F16 ? static_cast<const uint32_t*>(planes) : nullptr;
-    const uint16_t* wp = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0));
+    const uint16_t* wp = planes ? reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(planes) + (F16 ? WHDR_BYTES : 0))
+                                : nullptr;
     switch (hs) {
-        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st, hdr, bx);
-        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st, hdr, bx);
-        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st, hdr, bx);
-        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st, hdr, bx);
+        case 4: return launch_down<4>(L, wp, S, N, Cs, Cl, st, hdr, bx, zeroed);
+        case 8: return launch_down<8>(L, wp, S, N, Cs, Cl, st, hdr, bx, zeroed);
+        case 16: return launch_down<16>(L, wp, S, N, Cs, Cl, st, hdr, bx, zeroed);
+        case 32: return launch_down<32>(L, wp, S, N, Cs, Cl, st, hdr, bx, zeroed);
         default: return PGAN_EINVAL;
     }
+}
+int FN_DOWN(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+            int amax_per_sample, int amax_count, hipStream_t st) {
+    return down_entry(L, planes, S, N, Cs, Cl, hs, amax, amax_per_sample, amax_count, st, 0);
+}
+// The same for an output that already holds zeros where the launch needs them: launches that split K over two blocks add
+// into S and otherwise clear it first with a launch of their own; FN_DOWN_ADDS tells whether a shape is such a launch
+// (1 / 0; -1: invalid shape).  For other shapes this is FN_DOWN.
+int FN_DOWN_ZEROED(const float* L, const void* planes, float* S, int N, int Cs, int Cl, int hs, const float* amax,
+                   int amax_per_sample, int amax_count, hipStream_t st) {
+    return down_entry(L, planes, S, N, Cs, Cl, hs, amax, amax_per_sample, amax_count, st, 1);
+}
+int FN_DOWN_ADDS(int N, int Cs, int Cl, int hs) {
+    if (N <= 0) return 0;
+    const int r = down_entry(nullptr, nullptr, nullptr, N, Cs, Cl, hs, nullptr, 0, 0, nullptr, -1);
+    return r < 0 ? -1 : r;
 }
 
 // L[N,Cl,2H,2H] = conv_transpose2d(S[N,Cs,H,H], W, stride 2, pad 1) with W given as prepared planes.

@@ -62,16 +62,16 @@ const Entry ENTRIES[] = {
     PGAN_ENTRY(pgan_conv_down), PGAN_ENTRY(pgan_conv_down_gn_sums), PGAN_ENTRY(pgan_conv_up), PGAN_ENTRY(pgan_conv_wgrad),
     PGAN_ENTRY(pgan_rows_reduce), PGAN_ENTRY(pgan_rows_reduce_multi),
     PGAN_ENTRY(pgan_conv_x3_prep), PGAN_ENTRY(pgan_conv_x3_prep_multi), PGAN_ENTRY(pgan_conv_down_x3),
-    PGAN_ENTRY(pgan_conv_up_x3), PGAN_ENTRY(pgan_conv_wgrad_x3),
+    PGAN_ENTRY(pgan_conv_up_x3), PGAN_ENTRY(pgan_conv_wgrad_x3), PGAN_ENTRY(pgan_conv_down_x3_zeroed),
     PGAN_ENTRY(pgan_conv_h2_prep), PGAN_ENTRY(pgan_conv_h2_prep_multi), PGAN_ENTRY(pgan_conv_h2_forget),
-    PGAN_ENTRY(pgan_conv_down_h2), PGAN_ENTRY(pgan_conv_up_h2), PGAN_ENTRY(pgan_conv_wgrad_h2),
+    PGAN_ENTRY(pgan_conv_down_h2), PGAN_ENTRY(pgan_conv_up_h2), PGAN_ENTRY(pgan_conv_wgrad_h2), PGAN_ENTRY(pgan_conv_down_h2_zeroed),
     PGAN_ENTRY(pgan_gn_fwd), PGAN_ENTRY(pgan_gn_fwd_presummed), PGAN_ENTRY(pgan_gn_fwd_static), PGAN_ENTRY(pgan_gn_bwd),
     PGAN_ENTRY(pgan_gn_jvp), PGAN_ENTRY(pgan_gn_bwd2), PGAN_ENTRY(pgan_gn_bwd_onepass),
     PGAN_ENTRY(pgan_bn_fwd), PGAN_ENTRY(pgan_bn_bwd), PGAN_ENTRY(pgan_bn_fwd_sums), PGAN_ENTRY(pgan_bn_fwd_apply),
     PGAN_ENTRY(pgan_bn_bwd_sums), PGAN_ENTRY(pgan_bn_bwd_apply),
     PGAN_ENTRY(pgan_head_fwd), PGAN_ENTRY(pgan_head_seed), PGAN_ENTRY(pgan_head_wgrad),
     PGAN_ENTRY(pgan_interpolate), PGAN_ENTRY(pgan_gp_penalty), PGAN_ENTRY(pgan_div_penalty), PGAN_ENTRY(pgan_critic_loss),
-    PGAN_ENTRY(pgan_sum_scale), PGAN_ENTRY(pgan_act_bwd), PGAN_ENTRY(pgan_affine), PGAN_ENTRY(pgan_adam),
+    PGAN_ENTRY(pgan_sum_scale), PGAN_ENTRY(pgan_act_bwd), PGAN_ENTRY(pgan_affine), PGAN_ENTRY(pgan_zero_multi), PGAN_ENTRY(pgan_adam),
     PGAN_ENTRY(pgan_philox), PGAN_ENTRY(pgan_philox_slice), PGAN_ENTRY(pgan_take_batch), PGAN_ENTRY(pgan_take_batch_slice),
     PGAN_ENTRY(pgan_label_smooth), PGAN_ENTRY(pgan_mono_switch),
     PGAN_ENTRY(pgan_d1d_fwd), PGAN_ENTRY(pgan_d1d_bwd), PGAN_ENTRY(pgan_d1d_fwd_len), PGAN_ENTRY(pgan_d1d_bwd_len),

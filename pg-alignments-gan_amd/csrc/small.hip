@@ -233,9 +233,43 @@ __global__ void cursor_advance_kernel(int* cursor, int npool, int B) { cursor[0]
 
 inline int grid_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
+// up to ZERO_MAX buffers cleared in one launch (blockIdx.y selects the buffer); sizes in 16-byte units
+constexpr int ZERO_MAX = 16;
+struct ZeroSet {
+    f32x4* p[ZERO_MAX];
+    long long n4[ZERO_MAX];
+};
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroSet zs) {
+    f32x4* p = zs.p[blockIdx.y];
+    const long long n4 = zs.n4[blockIdx.y];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = z;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Clears n <= 16 device buffers (16-byte aligned, sizes multiples of 16 bytes) in one launch: the outputs of the
+// convolution launches of a step that add into zeroed memory (pgan_conv_down_*_zeroed), cleared together at the step's
+// start instead of by one launch each in the middle of the chains.
+int pgan_zero_multi(void* const* bufs, const long long* bytes, int n, hipStream_t st) {
+    if (n <= 0) return PGAN_OK;
+    if (n > ZERO_MAX || !bufs || !bytes) return PGAN_EINVAL;
+    ZeroSet zs;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!bufs[i] || bytes[i] <= 0 || bytes[i] % 16 || reinterpret_cast<uintptr_t>(bufs[i]) % 16) return PGAN_EINVAL;
+        zs.p[i] = static_cast<f32x4*>(bufs[i]);
+        zs.n4[i] = bytes[i] / 16;
+        most = zs.n4[i] > most ? zs.n4[i] : most;
+    }
+    for (int i = n; i < ZERO_MAX; ++i) { zs.p[i] = nullptr; zs.n4[i] = 0; }
+    long long bx = (most + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    zero_multi_kernel<<<dim3((unsigned)bx, (unsigned)n), 256, 0, st>>>(zs);
+    return pgan_launch_status();
+}
 
 int pgan_head_fwd(const float* h4, const float* f1, const float* w, const float* b, float* score, int N, int K2, int K1,
                   hipStream_t st) {

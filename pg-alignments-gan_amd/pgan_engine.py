@@ -279,6 +279,7 @@ class Engine:
         self._bn_parts = {}
         # The caller's stream and these three are the first streams a fresh process creates, one hardware queue each
         # (HIP serves a process's streams from 4 queues); streams created later (a collective library's) share them.
+        self._zeroed = set()      # (address, elements) of convolution outputs cleared ahead of their launch in this step
         self.side = SideStream(device)
         self.wside = SideStream(device)     # weight-gradient passes of the critic step, beside the backward chain
         self.gside = SideStream(device)     # generator forwards made one critic step ahead (FusedTrainer)
@@ -435,6 +436,7 @@ class Engine:
         rel = getattr(self.ops, "release_weights", None)
         if rel is not None:
             rel()
+        self._zeroed.clear()      # outputs cleared ahead of their convolutions: only within the step that cleared them
 
     def gen_forward(self, z: torch.Tensor, out_s: torch.Tensor, out_p: torch.Tensor) -> None:
         """(sites, positions) = G(z), BatchNorm in training mode (layers.py:143-147).  Activations
@@ -588,7 +590,7 @@ class Engine:
                              bound_l=up_max)
                 if self.gen_grad_ready is not None:
                     self.gen_grad_ready(f"twod_conv_layers.{3 * i}.weight")
-            o.conv_down(up, w, self.gdH[i], bound=up_max)
+            self._conv_down(up, w, self.gdH[i], bound=up_max)
             n = f"twod_conv_layers.{3 * (i - 1) + 1}"
             self._bn_bwd(n, self.gdH[i], self.gH[i], self.gA[i], self.gStat[i], G[n + ".weight"], self.gdA[i],
                          dG[n + ".weight"], dG[n + ".bias"], amax=self.gdAmax[i])
@@ -617,6 +619,33 @@ class Engine:
         """Bounds of dH[k][lo:hi] for the convolutions (stage 0 is the input image: single-channel kernels, no bound)."""
         return self.dHmax[k][lo:hi] if k >= 1 else None
 
+    # Convolution launches with small grids split their reduction over two blocks per tile that ADD into the output, which
+    # they otherwise clear first with a launch of their own in the middle of a chain.  The outputs of a step's launches of
+    # that kind are cleared together in one launch at the step's start instead (PGAN_ZERO_AHEAD=0: not).
+    zero_ahead = os.environ.get("PGAN_ZERO_AHEAD", "1") != "0"
+
+    def _zero_ahead(self, jobs) -> None:
+        """jobs: (output tensor, weight) of conv_down launches that follow in this step on streams ordered after this
+        point; nothing else may write those outputs before their launch."""
+        o = self.ops
+        if not (self.zero_ahead and hasattr(o, "zero_multi")):
+            return
+        todo = []
+        for y, w in jobs:
+            if y.numel() and o.conv_down_adds(y.shape[0], w.shape[0], w.shape[1], y.shape[2]):
+                todo.append(y)
+                self._zeroed.add((y.data_ptr(), y.numel()))
+        if todo:
+            o.zero_multi(todo)
+
+    def _conv_down(self, x, w, y, bound=None) -> None:
+        key = (y.data_ptr(), y.numel())
+        if key in self._zeroed:
+            self._zeroed.discard(key)
+            self.ops.conv_down(x, w, y, bound=bound, zeroed=True)
+        else:
+            self.ops.conv_down(x, w, y, bound=bound)
+
     def _d_forward2d(self, lo: int, hi: int) -> None:
         o = self.ops
         fused = getattr(o, "conv_down_gn_sums", None)      # first stage: the norm's statistics pass inside the convolution
@@ -627,7 +656,7 @@ class Engine:
                 o.gn_fwd(self.dA[1][lo:hi], gw, gb, self.dH[1][lo:hi], self.dStat[1][lo:hi], amax=self.dHmax[1][lo:hi],
                          **({"presummed": True} if pre else {}))
                 continue
-            o.conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi], bound=self._hmax(k - 1, lo, hi))
+            self._conv_down(self.dH[k - 1][lo:hi], self.dconv_w(k), self.dA[k][lo:hi], bound=self._hmax(k - 1, lo, hi))
             o.gn_fwd(self.dA[k][lo:hi], gw, gb, self.dH[k][lo:hi], self.dStat[k][lo:hi], amax=self.dHmax[k][lo:hi])
 
     def _d_backward1(self, lo: int, hi: int, g_lo: int, g_hi: int, g_out: Optional[torch.Tensor]) -> None:
@@ -742,6 +771,8 @@ class Engine:
             # Wasserstein chain goes first on the weight-gradient stream.
             if hasattr(o, "prepare_weights"):
                 o.prepare_weights([self.dconv_w(k) for k in range(1, nS + 1)])
+            self._zero_ahead([(self.dA[k][lo:hi], self.dconv_w(k)) for k in range(2, nS + 1)
+                              for lo, hi in ((0, 2 * B), (2 * B, NS), (NS, NT))])
             self.wside.fork()
             with self.wside:
                 self._d_forward2d(0, 2 * B)
@@ -758,6 +789,7 @@ class Engine:
         else:
             if self.loss == "gp":
                 o.interpolate(self.tbuf, self.X0[:B], self.X0[B:2 * B], self.X0[2 * B:3 * B])
+            self._zero_ahead([(self.dA[k][lo:hi], self.dconv_w(k)) for k in range(2, nS + 1) for lo, hi in ((0, NS), (NS, NT))])
             # primal forward
             self._d_forward2d(0, NS)
             self.side.wait_mark()
@@ -772,7 +804,7 @@ class Engine:
         # tangent forward of v through the 2-D tower (primal state = the penalised samples' slots)
         pl, ph = NS - NP, NS
         for k in range(1, nS + 1):
-            o.conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT], bound=self._hmax(k - 1, NS, NT))
+            self._conv_down(self.dH[k - 1][NS:NT], self.dconv_w(k), self.dA[k][NS:NT], bound=self._hmax(k - 1, NS, NT))
             gw_k, gb_k = self.dgn(k)
             o.gn_jvp(self.dA[k][NS:NT], self.dH[k][pl:ph], self.dA[k][pl:ph], self.dStat[k][pl:ph], gw_k,
                      self.dH[k][NS:NT], self.dStatT[k][NS:NT], amax=self.dHmax[k][NS:NT], beta=gb_k)
@@ -857,6 +889,8 @@ class Engine:
         o.affine(self.gXs, 1.0, 0.0, self.X0[:B])                          # copy
         if hasattr(o, "prepare_weights"):
             o.prepare_weights([self.dconv_w(k) for k in range(1, nS + 1)], hold=False)
+        self._zero_ahead([(self.dA[k][:B], self.dconv_w(k)) for k in range(2, nS + 1)]
+                         + [(self.gdH[i], self.G.p[f"twod_conv_layers.{3 * i}.weight"]) for i in range(self.nG, 0, -1)])
         self._d_forward2d(0, B)
         self.side.wait_mark()
         o.head_fwd(self.dH[nS][:B], self.F1[:B], Dp["out.weight"], Dp["out.bias"], self.score[:B])

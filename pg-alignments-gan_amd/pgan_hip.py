@@ -58,6 +58,11 @@ _SIGS = {
     "pgan_conv_h2_prep_multi": [P, P, P, P, I, P],
     "pgan_conv_x3_prep_multi": [P, P, P, P, I, P],
     "pgan_conv_down_h2": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_down_h2_zeroed": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_down_x3_zeroed": [P, P, P, I, I, I, I, P, I, I, P],
+    "pgan_conv_down_h2_adds": [I, I, I, I],
+    "pgan_conv_down_x3_adds": [I, I, I, I],
+    "pgan_zero_multi": [P, P, I, P],
     "pgan_conv_up_h2": [P, P, P, I, I, I, I, P, I, I, P],
     "pgan_conv_wgrad_h2": [P, P, P, P, L, I, I, I, I, I, I, I, P, I, I, P, I, I, P],
     "pgan_rows_reduce": [P, I, P, I, I, I, I, I, I, P],
@@ -191,7 +196,8 @@ class _Lib:
     _HOST = ("pgan_parse_alignments", "pgan_parse_ms", "pgan_step_graph_begin", "pgan_step_graph_end", "pgan_step_graph_launch",
              "pgan_step_graph_destroy", "pgan_event_create", "pgan_event_destroy", "pgan_tape_destroy", "pgan_tape_arg_count",
              "pgan_tape_append", "pgan_tape_length", "pgan_tape_replay", "pgan_gn_onepass_workspace_bytes",
-             "pgan_gn_onepass_workspace_init", "pgan_gn_onepass_workspace_error")
+             "pgan_gn_onepass_workspace_init", "pgan_gn_onepass_workspace_error", "pgan_conv_down_h2_adds",
+             "pgan_conv_down_x3_adds")
 
     def __init__(self, lib):
         self._real = lib
@@ -532,13 +538,41 @@ class HipOps:
             raise PganError(f"{what}: magnitude bound {float(have[i]):.6g} is below the operand's {float(true[i]):.6g} "
                             f"(row {i} of {tuple(bound.shape)}; operand {tuple(x.shape)})")
 
-    def conv_down(self, x, w, y, bound=None):
-        """bound: magnitude bounds of x from its producer (see _bound); without them the fp16-split kernel scans x."""
+    def conv_down_adds(self, N: int, Cs: int, Cl: int, hs: int) -> bool:
+        """True if conv_down at this shape adds into its output (a launch that splits its reduction over two blocks per
+        tile): such a launch clears the output first with a launch of its own unless conv_down(..., zeroed=True)."""
+        if not (self.split and Cl > 1):
+            return False
+        fn = _lib.pgan_conv_down_h2_adds if self.precision == "h2" else _lib.pgan_conv_down_x3_adds
+        return fn(N, Cs, Cl, hs) == 1
+
+    def zero_multi(self, tensors) -> None:
+        """Clear up to 16 contiguous tensors in one launch on the current stream."""
+        ts = [t for t in tensors if t.numel()]
+        for i in range(0, len(ts), 16):
+            part = ts[i:i + 16]
+            for t in part:
+                if not t.is_cuda or not t.is_contiguous() or (t.numel() * t.element_size()) % 16 or t.data_ptr() % 16:
+                    raise PganError("zero_multi: contiguous 16-byte aligned CUDA tensors of a multiple of 16 bytes")
+            n = len(part)
+            pa = (c_void_p * n)(*[t.data_ptr() for t in part])
+            ba = (c_longlong * n)(*[t.numel() * t.element_size() for t in part])
+            _check(_lib.pgan_zero_multi(pa, ba, n, _stream()), "pgan_zero_multi")
+
+    def conv_down(self, x, w, y, bound=None, zeroed=False):
+        """bound: magnitude bounds of x from its producer (see _bound); without them the fp16-split kernel scans x.
+        zeroed: y already holds zeros (cleared on a stream this launch is ordered after): a launch that adds into its
+        output (conv_down_adds) then does not clear it itself."""
         N, Cl, HL = x.shape[0], x.shape[1], x.shape[2]
         Cs, hs = w.shape[0], HL // 2
         assert tuple(y.shape) == (N, Cs, hs, hs) and w.shape[1] == Cl
         if self.split and Cl > 1:
             self._verify_bound("conv_down", x, N, bound)
+            if zeroed:
+                fn = _lib.pgan_conv_down_h2_zeroed if self.precision == "h2" else _lib.pgan_conv_down_x3_zeroed
+                _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
+                       "pgan_conv_down (split, zeroed output)")
+                return
             fn = _lib.pgan_conv_down_h2 if self.precision == "h2" else _lib.pgan_conv_down_x3
             _check(fn(_ptr(x), self._weight_planes(w), _ptr(y), N, Cs, Cl, hs, *_bound(bound, N), _stream()),
                    "pgan_conv_down (split)")
