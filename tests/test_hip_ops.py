@@ -954,3 +954,32 @@ def test_convolutions_at_bench_sizes(Cs, Cl, hs, N, precision):
     # the weight gradient over the whole batch against fp64 on the device
     want_w = torch.nn.grad.conv2d_weight(x.double(), w.shape, y.double(), stride=2, padding=1)
     close("conv_wgrad", dw, want_w.cpu())
+
+
+@pytest.mark.parametrize("precision", ["h2", "x3"])
+def test_conv_down_into_an_output_cleared_beforehand(precision):
+    """Launch shapes that split their reduction over two blocks per tile add into the output (conv_down_adds says which);
+    with the output cleared beforehand by zero_multi, conv_down(zeroed=True) gives the bits of the plain call, which clears
+    it itself; zero_multi clears several buffers of different sizes in one launch."""
+    from pgan_hip import HipOps
+    o = HipOps(torch.device(DEV), precision=precision)
+    g = torch.Generator(device="cpu").manual_seed(21)
+    adds = {(64, 512, 256, 4): True, (64, 256, 128, 8): True, (128, 512, 256, 4): True, (128, 128, 64, 16): False,
+            (320, 128, 64, 16): False}
+    outs = []
+    for (N, Cs, Cl, hs), want in adds.items():
+        assert o.conv_down_adds(N, Cs, Cl, hs) == want, (N, Cs, Cl, hs)
+        x = torch.randn(N, Cl, 2 * hs, 2 * hs, generator=g).to(DEV)
+        w = (torch.randn(Cs, Cl, 4, 4, generator=g) * 0.05).to(DEV)
+        plain = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+        ahead = torch.full((N, Cs, hs, hs), float("nan"), device=DEV)
+        o.conv_down(x, w, plain)
+        outs.append((x, w, plain, ahead))
+    o.zero_multi([t[3] for t in outs])
+    torch.cuda.synchronize()
+    assert all(float(t[3].abs().max()) == 0.0 for t in outs)
+    for x, w, plain, ahead in outs:
+        o.conv_down(x, w, ahead, zeroed=True)
+    torch.cuda.synchronize()
+    for x, w, plain, ahead in outs:
+        assert torch.isfinite(plain).all() and torch.equal(plain, ahead), tuple(x.shape)
