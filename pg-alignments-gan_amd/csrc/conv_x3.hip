@@ -521,8 +521,11 @@ __device__ __forceinline__ int lds_group_pixel(int j) {
 #ifndef PGAN_ABL_UP
 #define PGAN_ABL_UP 0
 #endif
-template <int HS, int BN, int NC>
-__global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2)) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
+// KG = 2 (NC = 1 only): two groups of four waves share the block's output tile and take the two halves of the block's cs
+// range, each with its own LDS buffers; group 1 hands its sums to group 0 through LDS at the end (a fixed order:
+// deterministic).  For launches whose grid gives a CU only one block: a second wave per SIMD to cover the other's waits.
+template <int HS, int BN, int NC, int KG = 1>
+__global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2))) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl,
                                                               int cl_major, const uint32_t* __restrict__ whdr, Bound by) {
     using T = PixTile<HS, BN>;
@@ -532,9 +535,13 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     constexpr int BM = 32 * NC, TN = BN / 32, NT = 256 * NC;
     constexpr int BPL = NP * 8;                                     // dwords per plane
     constexpr int NI = NP * 2, NQ = (NI + NT - 1) / NT;             // (pixel, channel octet) items per thread
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * NPL * BPL];
+    static_assert(KG == 1 || NC == 1, "wave groups along K only with one row tile per block");
+    constexpr int BUF2 = 2 * NPL * BPL, XCH = KG > 1 ? TN * 16 * 256 : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[KG * BUF2 > XCH ? KG * BUF2 : XCH];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+    uint32_t* const lds = lds_all + grp * BUF2;
+    const int tid = KG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
     // the pixel of the tile that column j of the MFMA tile stands for, and the bit that swaps a pixel's two LDS slots
     const int jp = WS >= 16 ? j : lds_group_pixel(j);
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         for (int r = 0; r < 16; ++r) { acc[tn][r] = 0.f; acl[tn][r] = 0.f; }
 
     // gridDim.y > 1: the cs range is split across blocks, which then add into a zeroed X
-    const int nk = Cs / (16 * (int)gridDim.y), k0 = blockIdx.y * nk;
+    const int nk = Cs / (16 * (int)gridDim.y * KG), k0 = ((int)blockIdx.y * KG + grp) * nk;
     // Weight fragments are loaded PD K steps ahead of their use.  With 32-pixel tiles a K step is 12 MFMAs per wave
     // (about 400 cycles) at one or two waves per SIMD -- less than an L2 round trip under load, and the waves sat parked
     // on s_waitcnt vmcnt for half of their cycles (hs = 4: 49-59 % by the SQ counters); two register sets, used in turn,
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
 #pragma unroll
                 for (int i = 0; i < 8; ++i) m = fmaxf(m, bval[q] ? fabsf(breg[q][i]) : 0.f);
         }
-        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds)));
+        ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds_all)));     // one scale for the whole block
         sx = pow2f(-ex);
     }
     gload(k0 * 16);
@@ -696,6 +703,17 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
     }
 
     const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
+    if constexpr (KG > 1) {       // group 1 -> LDS -> group 0 (the K loop ended on a barrier: the buffers are free)
+        float* xch = reinterpret_cast<float*>(lds_all);
+        if (grp == 1) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(tn * 16 + r) * 256 + tid] = combine(acc[tn][r], acl[tn][r]);
+        }
+        __syncthreads();
+        if (grp == 1) return;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = tn * 32 + jp;
@@ -706,8 +724,10 @@ __global__ __launch_bounds__(256 * NC, (BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((
         for (int r = 0; r < 16; ++r) {
             const int cl = cl0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float* dst = X + (((int64_t)n * Cl + cl) * HL + 2 * (oh0 + al) + ph) * WL + 2 * bl + pw;
-            if (gridDim.y > 1) atomicAdd(dst, combine(acc[tn][r], acl[tn][r]) * unscale);
-            else *dst = combine(acc[tn][r], acl[tn][r]) * unscale;
+            float v = combine(acc[tn][r], acl[tn][r]);
+            if constexpr (KG > 1) v += reinterpret_cast<const float*>(lds_all)[(tn * 16 + r) * 256 + tid];
+            if (gridDim.y > 1) atomicAdd(dst, v * unscale);
+            else *dst = v * unscale;
         }
     }
 }
@@ -1166,6 +1186,7 @@ int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs
 
 int g_dn_variant = 0, g_dn_ks = 0, g_up_variant = 0, g_up_ks = 0;   // tuning overrides (0 = by size)
 int g_up_order = 0;                                                 // 1: pixel-major, 2: row-tile-major block order
+int g_up_kg = 0;                                                    // 1: never two wave groups along K in UP
 
 template <int HS>
 int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
@@ -1203,13 +1224,20 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
     const uint16_t* up = WP + (size_t)NPL * Cs * Cl * 16;
     // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU, and always at hs = 4 (measured
     // 135 against 149 us at N = 320; the 64-pixel tile spills there unless its occupancy drops to 2 waves per SIMD)
-    int variant = g_up_variant ? g_up_variant : ((HS == 4 || (Cl / 32) * PixTile<HS, 64>::ntiles(N) < 512) ? 5 : 1);
+    const int b64 = (Cl / 32) * PixTile<HS, 64>::ntiles(N), b32 = (Cl / 32) * PixTile<HS, 32>::ntiles(N);
+    int variant = g_up_variant ? g_up_variant : ((HS == 4 || b64 < 512) ? 5 : 1);
+    // grids of at most one block per CU: two wave groups along K per block, on the widest tile that still gives such a
+    // grid (fp16 split, isolated: hs = 4, 64 samples 26.3 -> 23.0 us, 128 samples 40.1 -> 37.0; hs = 8, 64 samples 22.2 -> 19.3)
+    if (F16 && !g_up_variant && !g_up_kg && Cs % 32 == 0) variant = b32 <= 256 ? 6 : (b64 <= 256 ? 7 : variant);
     if ((variant == 3 || variant == 4) && Cl % 64) variant -= 2;
-    const int nc = (variant == 3 || variant == 4) ? 2 : 1, bn = variant == 5 ? 32 : ((variant & 1) ? 64 : 128);
+    if (variant == 6 && Cs % 32) variant = 5;
+    if (variant == 7 && Cs % 32) variant = 1;
+    const int nc = (variant == 3 || variant == 4) ? 2 : 1;
+    const int bn = (variant == 5 || variant == 6) ? 32 : ((variant & 1) ? 64 : 128);
     const int blocks = (Cl / (32 * nc)) * (bn == 128 ? PixTile<HS, 128>::ntiles(N)
                                                      : (bn == 64 ? PixTile<HS, 64>::ntiles(N) : PixTile<HS, 32>::ntiles(N)));
     int ks = g_up_ks ? g_up_ks : 1;
-    while (ks > 1 && Cs % (32 * ks)) ks >>= 1;
+    while (ks > 1 && Cs % (32 * ks * (variant >= 6 ? 2 : 1))) ks >>= 1;
     if (ks > 1 && hipMemsetAsync(X, 0, sizeof(float) * (size_t)N * Cl * HS * HS * 4, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g(blocks, ks);
     const int clm = g_up_order ? g_up_order - 1 : ((int64_t)Cs * Cl * 96 > (int64_t)N * Cs * HS * HS * 4);
@@ -1219,6 +1247,8 @@ int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int C
         case 3: conv_up_x3_kernel<HS, 64, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
         case 4: conv_up_x3_kernel<HS, 128, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
         case 5: conv_up_x3_kernel<HS, 32, 1><<<g, 256, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 6: conv_up_x3_kernel<HS, 32, 1, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
+        case 7: conv_up_x3_kernel<HS, 64, 1, 2><<<g, 512, 0, st>>>(Y, up, X, N, Cs, Cl, clm, whdr, by); break;
         default: return PGAN_EINVAL;
     }
     return pgan_launch_status();
@@ -1238,12 +1268,13 @@ int FN_SET_OPTION(const char* name, int value) {
     auto eq = [](const char* x, const char* y) { while (*x && *x == *y) { ++x; ++y; } return *x == *y; };
     if (eq(name, "down_variant") && value >= 0 && value <= 4) { g_dn_variant = value; return PGAN_OK; }
     if (eq(name, "down_ks") && value >= 0 && value <= 8) { g_dn_ks = value; return PGAN_OK; }
-    if (eq(name, "up_variant") && value >= 0 && value <= 5) { g_up_variant = value; return PGAN_OK; }
+    if (eq(name, "up_variant") && value >= 0 && value <= 7) { g_up_variant = value; return PGAN_OK; }
     if (eq(name, "up_order") && value >= 0 && value <= 2) { g_up_order = value; return PGAN_OK; }
     if (eq(name, "down_order") && value >= 0 && value <= 2) { g_dn_order = value; return PGAN_OK; }
     if (eq(name, "wg_bm") && (value == 0 || value == 64 || value == 128)) { g_wg_bm = value; return PGAN_OK; }
     if (eq(name, "wg_target") && (value == 0 || (value >= 64 && value <= 4096))) { g_wg_target = value; return PGAN_OK; }
     if (eq(name, "up_ks") && value >= 0 && value <= 8) { g_up_ks = value; return PGAN_OK; }
+    if (eq(name, "up_kg") && value >= 0 && value <= 1) { g_up_kg = value; return PGAN_OK; }
     return PGAN_EINVAL;
 }
 

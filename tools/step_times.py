@@ -1,6 +1,7 @@
 """Where an iteration's time goes, unprofiled: timing events recorded on the caller's stream inside the replayed launch tape --
 at the start of the iteration, after every critic step's Adam update, before and after the generator step -- averaged over
-ITERS replays (batch 64, gp, 5 critic steps).  The events are Python steps between native runs of the tape."""
+ITERS replays (batch 64, gp, 5 critic steps).  The events are Python steps between native runs of the tape.
+OPTS="name=value ..." sets tuning options of the split-operand convolution kernels first."""
 import os
 import sys
 
@@ -11,10 +12,12 @@ import torch
 
 import dcwgan_oracle as orc
 import pgan_tape
-from pgan_hip import HipOps
+from pgan_hip import HipOps, set_x3_option
 from pgan_trainer import FusedTrainer
 
 dev = torch.device("cuda:0")
+for kv in os.environ.get("OPTS", "").split():
+    set_x3_option(kv.split("=")[0], int(kv.split("=")[1]))
 B, CI, ITERS = int(os.environ.get("B", "64")), 5, int(os.environ.get("ITERS", "40"))
 tr = FusedTrainer(HipOps(dev), B, dev, loss=os.environ.get("LOSS", "gp"), critic_iter=CI, seed=5)
 tr.eng.D.load(orc.make_params(orc.disc_param_shapes(), 7))
