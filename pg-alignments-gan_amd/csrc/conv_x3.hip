@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     constexpr int LDS_WORDS = (KG > 1 && BM * BN > 2 * BUF * KG) ? BM * BN : 2 * BUF * KG;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[LDS_WORDS];
 
-    const int grp = (KG > 1) ? (int)(threadIdx.x >> 8) : 0;
+    const int grp = (KG > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // the same in all of a wave: scalar address arithmetic
     uint32_t* const lds = lds_all + grp * 2 * BUF;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WC, wn = wave % WC, j = lane & 31, h = lane >> 5;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
         const bool row_ok = (e < PE) && n < N && ih >= 0 && ih < HL;
         val0[q] = row_ok && pw >= 1;
         val1[q] = row_ok && pw < WS;
-        const uint32_t base = (uint32_t)((n * Cl * HL + ih) * WL + 2 * pw);
+        const uint32_t base = (uint32_t)((seg * Cl * HL + ih) * WL + 2 * pw);       // from the block's first sample
         off0[q] = val0[q] ? base - 1u : 0u;
         off1[q] = val1[q] ? base : 0u;
         // threads past the patch write a padding slot
@@ -333,15 +333,21 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     float breg[2][CLC][NQ][2];
     float sx = 1.f;        // fp16 split: the block's activations are staged times this power of two (2^-ex)
     int ex = 0;
+    // Loads through buffer descriptors: a lane's byte offset is a 32-bit register fixed before the K loop, the chunk
+    // moves a scalar offset -- no vector address arithmetic inside the loop.  X's descriptor starts at the block's first
+    // sample and ends with the tensor (reads past it return zero).
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) + (int64_t)n0 * Cl * HL * WL, 0, (int)min((int64_t)(N - n0) * Cl * HL * WL * 4, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(WP), 0, (int)((int64_t)NPL * Cs * Cl * 32), 0x00020000);
     auto gload = [&](auto setc, int cl0) {
         constexpr int ST = decltype(setc)::value;
 #pragma unroll
         for (int c = 0; c < CLC; ++c) {
-            const float* Xc = X + (int64_t)(cl0 + c) * HL * WL;
+            const int so = (cl0 + c) * (HL * WL * 4);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                breg[ST][c][q][0] = Xc[off0[q]];
-                breg[ST][c][q][1] = Xc[off1[q]];
+                breg[ST][c][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(off0[q] * 4u), so, 0));
+                breg[ST][c][q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(off1[q] * 4u), so, 0));
             }
         }
     };
@@ -350,7 +356,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
         constexpr int ST = decltype(setc)::value, it = decltype(itc)::value;
         constexpr int c = it / NQ, q = it % NQ;
         uint32_t p[NPL];
-        split3(val0[q] ? breg[ST][c][q][0] * sx : 0.f, val1[q] ? breg[ST][c][q][1] * sx : 0.f, p);
+        // (items outside the image hold finite values of other pixels, or the zero of a read past the tensor: times zero)
+        split3(breg[ST][c][q][0] * (val0[q] ? sx : 0.f), breg[ST][c][q][1] * (val1[q] ? sx : 0.f), p);
 #pragma unroll
         for (int i = 0; i < NPL; ++i) buf[i * BPL + c * CHW + loff[q]] = p[i];
     };
@@ -377,11 +384,11 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? ((BN == 64) ? 3 : 2) : 1) void 
     const size_t wplane = (size_t)Cl * Cs * 16;
     auto aload = [&](auto setc, int cl) {          // weight fragments of channel cl
         constexpr int set = decltype(setc)::value;
-        const uint16_t* Wc = WP + (size_t)cl * Cs * 16;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) a[set][tm][i] = *reinterpret_cast<const u32x4*>(Wc + i * wplane + abase[tm]);
+            for (int i = 0; i < NPL; ++i)
+                a[set][tm][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(abase[tm] * 2u), (cl * Cs * 16 + i * (int)wplane) * 2, 0));
     };
     auto ldops = [&](const uint32_t* buf, auto cc) {
         constexpr int c = decltype(cc)::value, set = c & 1;
@@ -521,6 +528,14 @@ __device__ __forceinline__ int lds_group_pixel(int j) {
 #ifndef PGAN_ABL_UP
 #define PGAN_ABL_UP 0
 #endif
+// PGAN_UP_TIMING (debugging builds only): thread 0 of the first 64 blocks of an UP launch notes the 100 MHz wall clock at
+// six points of the kernel; the debug entry point at the end of this file copies the notes out.
+#ifdef PGAN_UP_TIMING
+__device__ unsigned long long g_up_stamps[64][8];
+#define UP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0) g_up_stamps[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define UP_STAMP(i) do { } while (0)
+#endif
 // KG = 2 (NC = 1 only): two groups of four waves share the block's output tile and take the two halves of the block's cs
 // range, each with its own LDS buffers; group 1 hands its sums to group 0 through LDS at the end (a fixed order:
 // deterministic).  For launches whose grid gives a CU only one block: a second wave per SIMD to cover the other's waits.
@@ -528,6 +543,7 @@ template <int HS, int BN, int NC, int KG = 1>
 __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 && HS >= 8) ? 3 : ((BN >= 128 && NC == 1) ? 1 : 2))) void conv_up_x3_kernel(const float* __restrict__ Y, const uint16_t* __restrict__ WP,
                                                               float* __restrict__ X, int N, int Cs, int Cl,
                                                               int cl_major, const uint32_t* __restrict__ whdr, Bound by) {
+    UP_STAMP(0);
     using T = PixTile<HS, BN>;
     constexpr int WS = HS, HL = 2 * HS, WL = 2 * HS;
     constexpr int SEG = T::SEG, R = T::R;
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
     constexpr int BUF2 = 2 * NPL * BPL, XCH = KG > 1 ? TN * 16 * 256 : 0;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[KG * BUF2 > XCH ? KG * BUF2 : XCH];
 
-    const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+    const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // the same in all of a wave: scalar address arithmetic
     uint32_t* const lds = lds_all + grp * BUF2;
     const int tid = KG > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = (wave >> 1) & 1, pw = wave & 1, wc = wave >> 2, j = lane & 31, h = lane >> 5;
@@ -566,18 +582,26 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
         const int seg = p / (PR * PC), rem = p % (PR * PC), pr = rem / PC, pc = rem % PC;
         const int n = n0 + seg, a = oh0 - 1 + pr, bb = pc - 1;
         bval[q] = (e < NI) && n < N && a >= 0 && a < HS && bb >= 0 && bb < WS;
-        boff[q] = bval[q] ? (uint32_t)(((n * Cs + oct * 8) * HS + a) * WS + bb) : 0u;
+        boff[q] = bval[q] ? (uint32_t)(((seg * Cs + oct * 8) * HS + a) * WS + bb) : 0u;       // from the block's first sample
         blds[q] = (e < NI) ? p * 8 + ((oct ^ up_swz(seg * PR + pr, pc)) & 1) * 4 : -1;
     }
     float breg[NQ][8];
     float sx = 1.f;        // fp16 split: the block's activations are staged times this power of two (2^-ex)
     int ex = 0;
+    // Loads through buffer descriptors: a lane's byte offset is a 32-bit register fixed before the K loop, the K step
+    // moves a scalar offset, the channel / plane is an immediate -- no vector address arithmetic inside the loop (with
+    // 64-bit pointers it was 16 two-word adds per wave and K step beside 12 MFMAs).
+    // (Y's descriptor starts at the block's first sample and ends with the tensor: reads past it return zero)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Y) + (int64_t)n0 * Cs * HS * WS, 0, (int)min((int64_t)(N - n0) * Cs * HS * WS * 4, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(WP), 0, (int)((int64_t)NPL * Cs * Cl * 32), 0x00020000);
     auto gload = [&](int cs0) {
-        const float* Yc = Y + (int64_t)cs0 * HS * WS;
+        const int so = cs0 * (HS * WS * 4);
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) breg[q][i] = Yc[boff[q] + (bval[q] ? i * HS * WS : 0)];
+            for (int i = 0; i < 8; ++i)       // (items outside the image: channel i of pixel 0, not used)
+                breg[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)(boff[q] * 4u) + i * HS * WS * 4, so, 0));
     };
     auto lstore = [&](uint32_t* Bs) {
 #pragma unroll
@@ -586,7 +610,8 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t p3[NPL];
-                split3(bval[q] ? breg[q][2 * i] * sx : 0.f, bval[q] ? breg[q][2 * i + 1] * sx : 0.f, p3);
+                const float sq = bval[q] ? sx : 0.f;      // items outside the image hold finite values of other pixels: times zero
+                split3(breg[q][2 * i] * sq, breg[q][2 * i + 1] * sq, p3);
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) pk[pl][i] = p3[pl];
             }
@@ -641,9 +666,9 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
     u32x4 a[PD][4][NPL];
     auto aload = [&](auto d, int t, int ks) {         // weight fragments of tap t, K step ks, into register set d
         constexpr int D = decltype(d)::value;
-        const uint16_t* Wk = WP + (size_t)ks * Cl * 16;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) a[D][t][i] = *reinterpret_cast<const u32x4*>(Wk + i * wplane + aofs[t]);
+        for (int i = 0; i < NPL; ++i)
+            a[D][t][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(aofs[t] * 2u), (ks * Cl * 16 + i * (int)wplane) * 2, 0));
     };
     if constexpr (F16) {       // one pass over this block's patches for their largest magnitude -> the block's scale
         float m = 0.f;
@@ -658,6 +683,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
         ex = scale_exp(block_amax(m, reinterpret_cast<float*>(lds_all)));     // one scale for the whole block
         sx = pow2f(-ex);
     }
+    UP_STAMP(1);
     gload(k0 * 16);
     static_for<PD>([&](auto d) {
 #pragma unroll
@@ -666,6 +692,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
     lstore(lds);
     if (nk > 1) gload((k0 + 1) * 16);
     __syncthreads();
+    UP_STAMP(2);
     for (int kb = 0; kb < nk; kb += PD) {
         static_for<PD>([&](auto d) {
             constexpr int D = decltype(d)::value;
@@ -702,6 +729,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
         });
     }
 
+    UP_STAMP(3);
     const float unscale = F16 ? pow2f(ex) * pow2f(scale_exp(__builtin_bit_cast(float, whdr[0]))) : 1.f;
     if constexpr (KG > 1) {       // group 1 -> LDS -> group 0 (the K loop ended on a barrier: the buffers are free)
         float* xch = reinterpret_cast<float*>(lds_all);
@@ -714,6 +742,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
         __syncthreads();
         if (grp == 1) return;
     }
+    UP_STAMP(4);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int pt = tn * 32 + jp;
@@ -730,6 +759,7 @@ __global__ __launch_bounds__(256 * NC * KG, KG > 1 ? 1 : ((BN <= 64 && NC == 1 &
             else *dst = v * unscale;
         }
     }
+    UP_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1191,7 +1221,8 @@ int g_up_kg = 0;                                                    // 1: never 
 template <int HS>
 int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
                 Bound bx, int zeroed = 0) {
-    if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
+    // the kernel addresses a block's samples of X and the weight planes with 32-bit byte offsets
+    if ((int64_t)N * Cl * HS * HS * 4 >= (1ll << 31) || (int64_t)Cs * Cl * 32 * NPL * 2 >= (1ll << 31) || (int64_t)Cl * HS * HS * 16 * 64 >= (1ll << 31)) return PGAN_EINVAL;
     int variant = g_dn_variant, ks = g_dn_ks;
     if (variant == 0 || ks < 1) {
         // 128x64 tiles when they still give two blocks per CU, else 64x64 tiles (three blocks per CU);
@@ -1220,12 +1251,14 @@ template <int HS>
 int launch_up(const float* Y, const uint16_t* WP, float* X, int N, int Cs, int Cl, hipStream_t st, const uint32_t* whdr,
               Bound by) {
     if (Cl % 32 || Cs % 16) return PGAN_EINVAL;
-    if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 48 >= (1ll << 31)) return PGAN_EINVAL;
+    // the kernel addresses a block's samples of Y and the weight planes with 32-bit byte offsets
+    if ((int64_t)N * Cs * HS * HS >= (1ll << 31) || (int64_t)Cs * Cl * 32 * NPL * 2 >= (1ll << 31) || (int64_t)Cs * HS * HS * 64 >= (1ll << 31)) return PGAN_EINVAL;
     const uint16_t* up = WP + (size_t)NPL * Cs * Cl * 16;
     // 64-pixel tiles; 32-pixel tiles when those would give fewer than two blocks per CU, and always at hs = 4 (measured
     // 135 against 149 us at N = 320; the 64-pixel tile spills there unless its occupancy drops to 2 waves per SIMD)
     const int b64 = (Cl / 32) * PixTile<HS, 64>::ntiles(N), b32 = (Cl / 32) * PixTile<HS, 32>::ntiles(N);
-    int variant = g_up_variant ? g_up_variant : ((HS == 4 || b64 < 512) ? 5 : 1);
+    // (fp16 split: 64-pixel tiles from 1.5 blocks per CU on; at hs = 4 from two on -- 82.5 against 89.6 us at N = 320)
+    int variant = g_up_variant ? g_up_variant : (F16 ? ((HS == 4 && b64 < 512) ? 5 : 1) : ((HS == 4 || b64 < 512) ? 5 : 1));
     // grids of at most one block per CU: two wave groups along K per block, on the widest tile that still gives such a
     // grid (fp16 split, isolated: hs = 4, 64 samples 26.3 -> 23.0 us, 128 samples 40.1 -> 37.0; hs = 8, 64 samples 22.2 -> 19.3)
     if (F16 && !g_up_variant && !g_up_kg && Cs % 32 == 0) variant = b32 <= 256 ? 6 : (b64 <= 256 ? 7 : variant);
@@ -1405,5 +1438,12 @@ int FN_WGRAD(const float* S, const float* L, float* dW, float* ws, long long ws_
         default: return PGAN_EINVAL;
     }
 }
+
+#if defined(PGAN_UP_TIMING) && defined(PGAN_SPLIT_F16)
+// (debugging builds) the notes of the last UP launch: 64 blocks x 8 clock values, to host memory
+int pgan_h2_debug_up_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_up_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? PGAN_OK : PGAN_ELAUNCH;
+}
+#endif
 
 }  // extern "C"
