@@ -1230,7 +1230,7 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
         const int b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
         int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
         if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
-        else if (Cs % 128 == 0 && b4 >= 512 && Cl <= 64) { v = 2; k = 1; }       // short K: one 128x64 block per CU (18.5 against 21.2 us)
+        else if (Cs % 128 == 0 && b4 >= 512 && Cl <= 128) { v = 2; k = 1; }      // short K: one 128x64 block per CU (Cl = 64: 18.5 against 21.2 us; Cl = 128: 35.0 against 38.7)
         else if (Cs % 128 == 0 && b4 >= 512 && Cl >= 256) { v = 2; k = 2; }      // long K: 128x64 tiles, K over two blocks
         else if (Cs % 128 == 0 && b4 >= 256 && b4 < 512 && Cl >= 128) { v = 2; k = 4; }   // ... over two blocks x two wave groups
         while (k > 1 && Cl % (8 * k)) k >>= 1;
