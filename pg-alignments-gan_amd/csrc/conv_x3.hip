@@ -864,57 +864,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         }
     }
     float breg[NQB][NBR];
-    // block-uniform part of a chunk's addresses
+    // Block-uniform part of a chunk's addresses: a buffer descriptor per operand that starts at the chunk's first S row /
+    // L patch row and ends with the tensor.  A lane's byte offset into it is fixed before the K loop; a lane whose item
+    // does not exist in this chunk (sample past the batch, patch row above or below the image, no left / right neighbour)
+    // reads at an offset past every tensor, which returns zero without a branch -- the chunk body is one basic block.
     struct Src {
-        const char* ya;
-        const char* xb;
+        __amdgpu_buffer_rsrc_t ya, xb;
         int n0, out_mask;
     };
+    constexpr int NOWHERE = 0x7ffffff0;
+    const int64_t ya_bytes = (int64_t)N * Cs * (HS * HS) * 4, xb_bytes = (int64_t)N * xsample;
     auto src_of = [&](int chunk) {
         int n0, oh0;
         T::origin(chunk, n0, oh0);
         Src r;
-        r.ya = reinterpret_cast<const char*>(YA) + 4 * ((int64_t)n0 * Cs * (HS * HS) + oh0 * WS);
+        const int64_t ao = 4 * ((int64_t)n0 * Cs * (HS * HS) + oh0 * WS);
         // HS >= 8: rows 2 oh0 - 1 .. of sample r(n0); the base may point one row before the sample, which is never read
-        r.xb = reinterpret_cast<const char*>(X) +
-               (HS == 4 ? (int64_t)0 : (int64_t)remap(n0) * xsample + 4 * (2 * oh0 - 1) * WL);
+        const int64_t bo = HS == 4 ? (int64_t)0 : (int64_t)remap(n0) * xsample + 4 * (2 * oh0 - 1) * WL;
+        r.ya = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(YA)) + ao, 0,
+                                                 (int)min(ya_bytes - ao, (int64_t)0x7fffffff), 0x00020000);
+        r.xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(X)) + bo, 0,
+                                                 (int)min(xb_bytes - bo, (int64_t)0x7fffffff), 0x00020000);
         r.n0 = n0;
         r.out_mask = (oh0 == 0 ? 2 : 0) | (oh0 + R == HS ? 4 : 0);      // patch rows outside the image
         return r;
+    };
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& rs, int off) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    };
+    auto ld1 = [](const __amdgpu_buffer_rsrc_t& rs, int off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
     };
     constexpr int NST = AV + NQB;         // staging items per thread and chunk: S first, then L
     auto load_item = [&](auto itc, const Src& sc) {
         constexpr int it = decltype(itc)::value;
         if constexpr (it < AV) {
             constexpr int q = it;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (SEG == 1 || sc.n0 + a_seg[q] < N) v = *reinterpret_cast<const f32x4*>(sc.ya + a_off[q]);
-            areg[q] = v;
+            areg[q] = ld4(sc.ya, (int)a_off[q]);        // a sample past the batch lies past the end of S
         } else if constexpr (HS == 4) {
             constexpr int q = it - AV;
             const int n = sc.n0 + (tid + 256 * q) / (CLB * 16);
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-            if ((b_flag[q] & 33) == 33 && n < N) {
-                const char* src = sc.xb + ((uint32_t)remap(n) * xsample + b_off[q]);
-                v0 = *reinterpret_cast<const f32x4*>(src);
-                v1 = *reinterpret_cast<const f32x4*>(src + 16);
-            }
+            const int off = ((b_flag[q] & 33) == 33 && n < N) ? (int)((uint32_t)remap(n) * xsample + b_off[q]) : NOWHERE;
+            const f32x4 v0 = ld4(sc.xb, off), v1 = ld4(sc.xb, off + 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { breg[q][i] = v0[i]; breg[q][4 + i] = v1[i]; }
         } else {
             constexpr int q = it - AV;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            float lft = 0.f, rgt = 0.f;
-            if ((b_flag[q] & 1) && !(b_flag[q] & sc.out_mask)) {
-                const char* src = sc.xb + b_off[q];
-                v = *reinterpret_cast<const f32x4*>(src);
-                if (b_flag[q] & 8) lft = *reinterpret_cast<const float*>(src - 4);
-                if (b_flag[q] & 16) rgt = *reinterpret_cast<const float*>(src + 16);
-            }
-            breg[q][0] = lft;
+            const bool row = (b_flag[q] & 1) && !(b_flag[q] & sc.out_mask);
+            const f32x4 v = ld4(sc.xb, row ? (int)b_off[q] : NOWHERE);
+            breg[q][0] = ld1(sc.xb, (row && (b_flag[q] & 8)) ? (int)b_off[q] - 4 : NOWHERE);
 #pragma unroll
             for (int i = 0; i < 4; ++i) breg[q][1 + i] = v[i];
-            breg[q][5] = rgt;
+            breg[q][5] = ld1(sc.xb, (row && (b_flag[q] & 16)) ? (int)b_off[q] + 16 : NOWHERE);
         }
     };
     // split item `it` of the registers into the LDS image at `img` (A planes, then B planes)
