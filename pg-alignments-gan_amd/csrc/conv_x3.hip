@@ -872,7 +872,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float* __restr
         __amdgpu_buffer_rsrc_t ya, xb;
         int n0, out_mask;
     };
-    constexpr int NOWHERE = 0x7ffffff0;
+    // (2^31 as an unsigned byte offset: past every descriptor here, whose sizes are capped at 2^31 - 1 -- also when more
+    // than that remains of a tensor behind the chunk, where a smaller offset would read real values)
+    constexpr int NOWHERE = (int)0x80000000u;
     const int64_t ya_bytes = (int64_t)N * Cs * (HS * HS) * 4, xb_bytes = (int64_t)N * xsample;
     auto src_of = [&](int chunk) {
         int n0, oh0;
