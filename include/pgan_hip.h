@@ -82,7 +82,8 @@ long long pgan_conv_wgrad_x3_workspace_floats(int N, int Cs, int Cl, int hs);
 int pgan_conv_wgrad_x3(const float* S, const float* L, float* dW, float* ws, long long ws_floats, int N, int Cs, int Cl,
                        int hs, int n_keep, int n_swap, int accumulate, const float* amax_s, int amax_s_per_sample,
                        int amax_s_count, const float* amax_l, int amax_l_per_sample, int amax_l_count, hipStream_t st);
-/* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant", "up_ks", "up_order",
+/* tile overrides of those kernels for tuning runs ("down_variant", "down_ks", "up_variant" (6, 7: two wave groups
+ * along K per block), "up_ks", "up_kg" = 1: never two wave groups in UP, "up_order", "down_order", "wg_bm",
  * "wg_target" = blocks the weight-gradient split aims at; 0 = by size) */
 int pgan_x3_set_option(const char* name, int value);
 
