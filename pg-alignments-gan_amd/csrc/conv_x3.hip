@@ -1200,19 +1200,20 @@ int launch_wgrad(const float* YA, const float* X, float* dW, float* ws, int64_t 
 }
 
 int g_dn_order = 0;      // tuning override "down_order": 1 pixel-tile-major, 2 row-tile-major block order (0 = by size)
-// ks: 1 | 2 (blocks along K, two-addend sums) | 4 (two blocks of two wave groups each)
+// ks: 1 | 2 (blocks along K, two-addend sums) | 3 (one block of two wave groups: no sums through memory) | 4 (two blocks of
+// two wave groups each)
 // zeroed: the caller states that Y holds zeros already (K-split launches add into it); -1 only asks whether this launch
 // would need them (returns 1 / 0, launches nothing)
 template <int HS, int BM, int BN, int CLC>
 int launch_down_tile(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int Cl, int ks, hipStream_t st,
                      const uint32_t* whdr, Bound bx, int zeroed) {
-    if (Cs % BM || Cl % (2 * CLC * ks) || (ks != 1 && ks != 2 && ks != 4)) return PGAN_EINVAL;
-    const int gy = ks > 1 ? 2 : 1;
+    if (ks < 1 || ks > 4 || Cs % BM || Cl % (2 * CLC * (ks == 3 ? 2 : ks))) return PGAN_EINVAL;
+    const int gy = (ks == 2 || ks == 4) ? 2 : 1;
     if (zeroed < 0) return gy > 1;
     if (gy > 1 && !zeroed && hipMemsetAsync(Y, 0, sizeof(float) * (size_t)N * Cs * HS * HS, st) != hipSuccess) return PGAN_ELAUNCH;
     const dim3 g((Cs / BM) * PixTile<HS, BN>::ntiles(N), gy);
     const int csm = g_dn_order ? g_dn_order - 1 : ((int64_t)Cs * Cl * 16 * NPL * 2 > (int64_t)N * Cl * HS * HS * 16);
-    if (ks == 4) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
+    if (ks >= 3) conv_down_x3_kernel<HS, BM, BN, CLC, 2><<<g, 512, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
     else conv_down_x3_kernel<HS, BM, BN, CLC, 1><<<g, 256, 0, st>>>(X, WP, Y, N, Cs, Cl, whdr, bx, csm);
     return pgan_launch_status();
 }
@@ -1233,14 +1234,18 @@ int launch_down(const float* X, const uint16_t* WP, float* Y, int N, int Cs, int
         const int b4 = (Cs / 64) * PixTile<HS, 64>::ntiles(N);
         int v = 4, k = b4 >= 512 ? 1 : (b4 * 2 >= 512 ? 2 : 4);
         if (Cs % 128 == 0 && b4 >= 1024) { v = 2; k = 1; }
+        // (ks = 3 -- one block of two wave groups per tile, no sums through memory -- is faster in isolation where a grid has
+        // at most one block per CU and K is short (N = 128, hs = 8: 30.6 against 35.4 us; N = 64, hs = 8: 21.5 against 22.9),
+        // and costs the iteration 5 % when chosen there: eight waves with the registers of a 128x64 tile leave the other
+        // streams' blocks no room on the CU.  Not chosen by size; kept as a tuning option.)
         else if (Cs % 128 == 0 && b4 >= 512 && Cl <= 128) { v = 2; k = 1; }      // short K: one 128x64 block per CU (Cl = 64: 18.5 against 21.2 us; Cl = 128: 35.0 against 38.7)
         else if (Cs % 128 == 0 && b4 >= 512 && Cl >= 256) { v = 2; k = 2; }      // long K: 128x64 tiles, K over two blocks
         else if (Cs % 128 == 0 && b4 >= 256 && b4 < 512 && Cl >= 128) { v = 2; k = 4; }   // ... over two blocks x two wave groups
-        while (k > 1 && Cl % (8 * k)) k >>= 1;
+        while (k > 1 && k != 3 && Cl % (8 * k)) k >>= 1;
         if (variant == 0) variant = v;
         if (ks < 1) ks = k;
     }
-    if (ks == 3 || ks > 4) return PGAN_EINVAL;
+    if (ks > 4) return PGAN_EINVAL;
     switch (variant) {
         case 1: return launch_down_tile<HS, 128, 128, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);
         case 2: return launch_down_tile<HS, 128, 64, 4>(X, WP, Y, N, Cs, Cl, ks, st, whdr, bx, zeroed);

@@ -1,4 +1,4 @@
-"""KIND=down: the same for DOWN over ("down_variant" 1-4 = 128x128, 128x64, 64x128, 64x64 tiles; "down_ks" 1, 2, 4), the
+"""KIND=down: the same for DOWN over ("down_variant" 1-4 = 128x128, 128x64, 64x128, 64x64 tiles; "down_ks" 1, 2, 4 blocks x groups along K, 3 = two wave groups in one block), the
 clear of a K-split launch's output included.
 Isolated time of the fp16-split UP kernel on the launch shapes of an iteration per (tuning option "up_variant", "up_ks"):
 variants 5 / 1 are 32- / 64-pixel tiles, 6 / 7 the same with two wave groups per block along K; up_ks > 1 splits K over
@@ -41,7 +41,7 @@ def timed(fn, reps=200):
 
 combos = [(0, 0), (5, 0), (1, 0), (6, 0), (7, 0), (0, 0)]
 if KIND == "down":
-    combos = [(0, 0), (4, 1), (4, 2), (4, 4), (2, 1), (2, 2), (2, 4), (0, 0)]
+    combos = [(0, 0), (4, 1), (4, 3), (4, 4), (2, 1), (2, 3), (2, 4), (0, 0)]
 for N in [int(v) for v in os.environ.get("NS", "64,128").split(",")]:
     for Cs, Cl, hs in ((512, 256, 4), (256, 128, 8), (128, 64, 16)):
         y = torch.randn(N, Cs, hs, hs, generator=g).to(dev)
