@@ -169,15 +169,20 @@ __device__ __forceinline__ void conv1d_bwd(const float* d, const float* in, cons
     if (din) {
         for (int idx = threadIdx.x; idx < CI * LI; idx += blockDim.x) {
             const int ci = idx / LI, li = idx % LI;
+            const bool c0 = li < LO, c1 = li >= 1 && li - 1 < LO, c2 = li >= 2 && li - 2 < LO, c3 = li >= 3;
             float s = 0.f;
 #pragma unroll 4
             for (int co = 0; co < CO; ++co) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (co * CI + ci) * 4);
+                // all four reads are made and the ones outside the row dropped by a select: with a branch around each
+                // read the loop is a chain of LDS round trips (a read up to three floats outside the array stays inside
+                // the block's LDS or returns zero)
                 const float* dp = d + co * LO + li;
-                if (li < LO) s = fmaf(dp[0], wv[0], s);
-                if (li >= 1 && li - 1 < LO) s = fmaf(dp[-1], wv[1], s);
-                if (li >= 2 && li - 2 < LO) s = fmaf(dp[-2], wv[2], s);
-                if (li >= 3) s = fmaf(dp[-3], wv[3], s);
+                const float d0 = dp[0], d1 = dp[-1], d2 = dp[-2], d3 = dp[-3];
+                s = fmaf(c0 ? d0 : 0.f, wv[0], s);
+                s = fmaf(c1 ? d1 : 0.f, wv[1], s);
+                s = fmaf(c2 ? d2 : 0.f, wv[2], s);
+                s = fmaf(c3 ? d3 : 0.f, wv[3], s);
             }
             din[idx] = s;
         }
