@@ -72,7 +72,7 @@ def test_conv_down(hip, Cs, Cl, hs, N, kg):
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N", [5, 8])
-@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (2, 1), (2, 2), (3, 1), (4, 1), (4, 4)])
+@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (2, 1), (2, 2), (2, 3), (3, 1), (4, 1), (4, 3), (4, 4)])
 @pytest.mark.parametrize("split", ["x3", "h2"])
 def test_conv_down_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks, split):
     """Split operands on the 16-bit matrix pipe (six products of three bf16 planes / three products of two fp16
@@ -120,7 +120,7 @@ def test_conv_up(hip, Cs, Cl, hs, N, mode):
 
 @pytest.mark.parametrize("Cs,Cl,hs", LAYERS_X3)
 @pytest.mark.parametrize("N", [5, 8])
-@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2), (3, 1), (4, 1), (5, 1)])
+@pytest.mark.parametrize("variant,ks", [(0, 0), (1, 1), (1, 4), (2, 1), (2, 2), (3, 1), (4, 1), (5, 1), (6, 1), (6, 2), (7, 1)])
 @pytest.mark.parametrize("split", ["x3", "h2"])
 def test_conv_up_bf16_pipe(hip, Cs, Cl, hs, N, variant, ks, split):
     from pgan_hip import set_x3_option
